@@ -1,0 +1,173 @@
+"""Python big-integer restatement of the reference's Anemoi path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the second, independent oracle (the first is `oracle/anemoi_oracle.c`).
+It exists to (1) cross-check the C oracle, (2) be pinned against every known-answer
+vector of the reference (`tests/golden/kats.json`, text-extracted from the reference's
+`#[test]` functions) and (3) mint extra golden vectors for the cases the reference's own
+tests leave unpinned (partial last chunk, empty input, 10 KB messages, random compress,
+Merkle roots) -- see `tools/mint_goldens.py`.
+
+Only `tests/`, `tools/mint_goldens.py`, `__graft_entry__.smoke()` and `bench.py`'s
+cpu_baseline leg may import it.  The product (`anemoi-rust_amd/`) never does.
+
+Parity status: PINNED -- reproduces all 14 x {10 sbox, 10 hash_field, 4 hash_bytes, 4 jive}
++ 7 x 4 compress_k(4) reference KATs (tests/test_oracle.py).
+
+Everything works on canonical integers in [0, p); Montgomery form is a representation
+detail of the C-ABI and is handled in `to_mont` / `from_mont` only.
+
+Reference lines followed (relative to the reference crate root):
+  mul_by_generator   src/traits.rs:78-91     (value-level: g*x mod p)
+  ark_layer          src/traits.rs:111-125
+  mds_layer          src/traits.rs:136-157   (arms NUM_COLUMNS = 1, 2)
+  sbox_layer         src/traits.rs:326-358
+  round/permutation  src/traits.rs:361-378
+  hash (bytes)       src/<f>/anemoi_2_1/hasher.rs:18-66, anemoi_4_3/hasher.rs:19-91
+  hash_field         src/<f>/anemoi_2_1/hasher.rs:68-85, anemoi_4_3/hasher.rs:93-129
+  merge              src/<f>/anemoi_2_1/hasher.rs:87-92, anemoi_4_3/hasher.rs:131-145
+  compress           src/<f>/anemoi_2_1/hasher.rs:96-103, anemoi_4_3/hasher.rs:148-160
+  compress_k         src/<f>/anemoi_2_1/hasher.rs:105-110, anemoi_4_3/hasher.rs:162-179
+  digest to_bytes    src/<f>/anemoi_*/digest.rs:42-46 (LE canonical bytes, 32 or 48)
+"""
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PARAMS = os.path.join(os.path.dirname(_HERE), "tests", "golden", "params.json")
+
+FIELD_IDS = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
+
+
+class Instance:
+    """One (field, width) Anemoi instantiation; all values canonical ints."""
+
+    def __init__(self, field, width, params=None):
+        if params is None:
+            with open(_PARAMS) as f:
+                params = json.load(f)
+        fp = params[field]
+        inst = fp["instances"]["anemoi_2_1" if width == 2 else "anemoi_4_3"]
+        self.field, self.width = field, width
+        self.p = int(fp["modulus"])
+        self.limbs = fp["u64_limbs"]
+        self.nbytes = 8 * self.limbs
+        self.chunk = fp["byte_chunk"]
+        self.alpha, self.inv_alpha = fp["alpha"], int(fp["inv_alpha"])
+        self.g, self.delta = fp["beta"], int(fp["delta"])
+        self.cols, self.rate = inst["num_columns"], inst["rate_width"]
+        self.rounds = inst["num_rounds"]
+        self.C = [int(v) for v in inst["ark_c"]]
+        self.D = [int(v) for v in inst["ark_d"]]
+        self.R = pow(2, 64 * self.limbs, self.p)
+        self.Rinv = pow(self.R, -1, self.p)
+
+    # ---- representation helpers (C-ABI encoding: N LE u64 limbs, Montgomery, R = 2^(64N)) ----
+    def to_mont(self, v):
+        return v * self.R % self.p
+
+    def from_mont(self, v):
+        return v * self.Rinv % self.p
+
+    # ---- permutation ----
+    def ark_layer(self, st, r):
+        c, p = self.cols, self.p
+        for i in range(c):
+            st[i] = (st[i] + self.C[r * c + i]) % p
+            st[c + i] = (st[c + i] + self.D[r * c + i]) % p
+
+    def mds_layer(self, st):
+        p, g = self.p, self.g
+        if self.cols == 1:
+            st[1] = (st[1] + st[0]) % p
+            st[0] = (st[0] + st[1]) % p
+        elif self.cols == 2:
+            st[0] = (st[0] + g * st[1]) % p
+            st[1] = (st[1] + g * st[0]) % p
+            st[3] = (st[3] + g * st[2]) % p
+            st[2] = (st[2] + g * st[3]) % p
+            st[2], st[3] = st[3], st[2]
+            st[2] = (st[2] + st[0]) % p
+            st[3] = (st[3] + st[1]) % p
+            st[0] = (st[0] + st[2]) % p
+            st[1] = (st[1] + st[3]) % p
+        else:
+            raise ValueError("no shipped instance has NUM_COLUMNS > 2")
+
+    def sbox_layer(self, st):
+        c, p, g = self.cols, self.p, self.g
+        for i in range(c):
+            x, y = st[i], st[c + i]
+            x = (x - g * y * y) % p
+            y = (y - pow(x, self.inv_alpha, p)) % p
+            x = (x + g * y * y + self.delta) % p
+            st[i], st[c + i] = x, y
+
+    def permutation(self, st):
+        assert len(st) == self.width
+        for r in range(self.rounds):
+            self.ark_layer(st, r)
+            self.mds_layer(st)
+            self.sbox_layer(st)
+        self.mds_layer(st)
+        return st
+
+    # ---- Jive ----
+    def compress(self, elems):
+        return self.compress_k(elems, 2)
+
+    def compress_k(self, elems, k):
+        assert len(elems) == self.width
+        if self.width == 2:
+            assert k == 2
+        assert self.width % k == 0 and k % 2 == 0
+        st = self.permutation(list(elems))
+        c = self.width // k
+        return [sum(elems[i + c * j] + st[i + c * j] for j in range(k)) % self.p for i in range(c)]
+
+    # ---- Sponge ----
+    def hash_field(self, elems):
+        st, i, rate = [0] * self.width, 0, self.rate
+        for e in elems:
+            st[i] = (st[i] + e) % self.p
+            i += 1
+            if i == rate:
+                self.permutation(st)
+                i = 0
+        sigma = 1 if len(elems) % rate == 0 else 0
+        st[self.width - 1] = (st[self.width - 1] + sigma) % self.p
+        if sigma == 0:
+            st[i] = (st[i] + 1) % self.p
+            self.permutation(st)
+        return st[0]
+
+    def bytes_to_elems(self, data):
+        """31/47-byte LE chunks; a SHORT last chunk gets a 0x01 byte appended."""
+        ch, out = self.chunk, []
+        for off in range(0, len(data), ch):
+            piece = data[off:off + ch]
+            v = int.from_bytes(piece, "little")
+            if len(piece) < ch:
+                v |= 1 << (8 * len(piece))
+            out.append(v % self.p)
+        return out
+
+    def hash(self, data):
+        return self.hash_field(self.bytes_to_elems(bytes(data)))
+
+    def merge(self, left, right):
+        if self.width == 2:
+            return self.compress([left, right])[0]
+        # reference behaviour (hasher.rs:136-138): digests[0] goes into BOTH rate cells
+        st = [left, left] + [0] * (self.width - 2)
+        return self.permutation(st)[0]
+
+    def digest_to_bytes(self, d):
+        return d.to_bytes(self.nbytes, "little")
+
+    # ---- Merkle (new surface; reduces to merge()) ----
+    def merkle_root(self, leaves):
+        level = list(leaves)
+        assert len(level) & (len(level) - 1) == 0 and level
+        while len(level) > 1:
+            level = [self.merge(level[2 * i], level[2 * i + 1]) for i in range(len(level) // 2)]
+        return level[0]

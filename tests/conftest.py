@@ -1,0 +1,40 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "anemoi-rust_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FIELD_IDS = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
+INSTANCES = [(f, w) for f in FIELD_IDS for w in (2, 4)]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def inst_key(field, width):
+    return "%s/anemoi_%s" % (field, "2_1" if width == 2 else "4_3")
+
+
+@pytest.fixture(scope="session")
+def kats():
+    with open(os.path.join(ROOT, "tests", "golden", "kats.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def params():
+    with open(os.path.join(ROOT, "tests", "golden", "params.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import orc
+    orc.build()
+    return orc.Oracle()
