@@ -1,0 +1,274 @@
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+
+FIELD_IDS = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
+ALL_DEVICES = -1
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_sz = ctypes.c_size_t
+_int = ctypes.c_int
+_vp = ctypes.c_void_p
+
+
+class AnemoiError(RuntimeError):
+    """An error code from the C-ABI (the reference's assert! panics map to ANEMOI_ERR_ARG = -3)."""
+
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__("anemoi_mi355x error %d: %s%s" % (code, _strerror(code), (" (%s)" % detail) if detail else ""))
+
+
+def lib_path():
+    return os.environ.get("ANEMOI_MI355X_LIB", os.path.join(_ROOT, "lib", "libanemoi_mi355x.so"))
+
+
+def _load():
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "libanemoi_mi355x.so not found at %s: build it with `make -C anemoi-rust_amd -j8` "
+            "(or __graft_entry__.build()). There is no CPU fallback." % path)
+    # PyTorch (device memory / streams plumbing in bench.py and tests) bundles its own HIP runtime;
+    # load it first so this library binds to the same libamdhip64 instance.
+    if os.environ.get("ANEMOI_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    return ctypes.CDLL(path)
+
+
+lib = _load()
+
+_SIGS = {
+    "anemoi_abi_version": ([], _int),
+    "anemoi_device_count": ([], _int),
+    "anemoi_strerror": ([_int], ctypes.c_char_p),
+    "anemoi_last_error": ([], ctypes.c_char_p),
+    "anemoi_field_id": ([ctypes.c_char_p], _int),
+    "anemoi_field_name": ([_int], ctypes.c_char_p),
+    "anemoi_field_limbs": ([_int], _int),
+    "anemoi_field_chunk_bytes": ([_int], _int),
+    "anemoi_num_rounds": ([_int, _int], _int),
+    "anemoi_permutation_batch": ([_int, _int, _u64p, _sz, _int], _int),
+    "anemoi_sbox_layer_batch": ([_int, _int, _u64p, _sz, _int], _int),
+    "anemoi_sbox_layer_dev": ([_int, _int, _vp, _sz, _vp], _int),
+    "anemoi_jive_compress_batch": ([_int, _int, _u64p, _u64p, _sz, _int], _int),
+    "anemoi_jive_compress_k_batch": ([_int, _int, _int, _u64p, _u64p, _sz, _int], _int),
+    "anemoi_merge_batch": ([_int, _u64p, _u64p, _sz, _int], _int),
+    "anemoi_hash_field_batch": ([_int, _int, _u64p, _sz, _sz, _u64p, _int], _int),
+    "anemoi_hash_bytes_batch": ([_int, _int, _u8p, _sz, _sz, _u64p, _int], _int),
+    "anemoi_merkle_root": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
+    "anemoi_to_montgomery": ([_int, _u64p, _u64p, _sz, _int], _int),
+    "anemoi_from_montgomery": ([_int, _u64p, _u64p, _sz, _int], _int),
+    "anemoi_permutation_dev": ([_int, _int, _vp, _sz, _vp], _int),
+    "anemoi_jive_compress_k_dev": ([_int, _int, _int, _vp, _vp, _sz, _vp], _int),
+    "anemoi_hash_field_dev": ([_int, _int, _vp, _sz, _sz, _vp, _vp], _int),
+    "anemoi_hash_bytes_dev": ([_int, _int, _vp, _sz, _sz, _vp, _vp], _int),
+    "anemoi_merkle_root_dev": ([_int, _vp, ctypes.c_uint, _vp, _vp, _vp], _int),
+    "anemoi_to_montgomery_dev": ([_int, _vp, _vp, _sz, _vp], _int),
+    "anemoi_from_montgomery_dev": ([_int, _vp, _vp, _sz, _vp], _int),
+}
+for _name, (_args, _res) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not export the header's symbol
+    _fn.argtypes, _fn.restype = _args, _res
+
+
+def _strerror(code):
+    return lib.anemoi_strerror(code).decode()
+
+
+def _check(rc):
+    if rc != 0:
+        raise AnemoiError(rc, lib.anemoi_last_error().decode() if rc == -4 else "")
+
+
+def device_count():
+    n = lib.anemoi_device_count()
+    if n < 0:
+        raise AnemoiError(n, lib.anemoi_last_error().decode())
+    return n
+
+
+def field_id(field):
+    if isinstance(field, str):
+        fid = lib.anemoi_field_id(field.encode())
+        if fid < 0:
+            raise AnemoiError(fid)
+        return fid
+    return int(field)
+
+
+def _p64(a):
+    return a.ctypes.data_as(_u64p)
+
+
+def _p8(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def ints_to_limbs(ints, limbs):
+    return np.array([[(int(v) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(limbs)] for v in ints],
+                    dtype=np.uint64).reshape(-1, limbs)
+
+
+def limbs_to_ints(arr):
+    arr = np.asarray(arr, dtype=np.uint64)
+    arr = arr.reshape(-1, arr.shape[-1])
+    return [sum(int(arr[r, i]) << (64 * i) for i in range(arr.shape[1])) for r in range(arr.shape[0])]
+
+
+def to_montgomery(field, canon, device=0):
+    """canonical little-endian limbs (rows of `limbs` uint64) -> Montgomery elements, on the GPU."""
+    fid = field_id(field)
+    a = np.ascontiguousarray(canon, dtype=np.uint64)
+    out = np.empty_like(a)
+    _check(lib.anemoi_to_montgomery(fid, _p64(a), _p64(out), a.size // lib.anemoi_field_limbs(fid), device))
+    return out
+
+
+def from_montgomery(field, mont, device=0):
+    fid = field_id(field)
+    a = np.ascontiguousarray(mont, dtype=np.uint64)
+    out = np.empty_like(a)
+    _check(lib.anemoi_from_montgomery(fid, _p64(a), _p64(out), a.size // lib.anemoi_field_limbs(fid), device))
+    return out
+
+
+class Anemoi:
+    """One (field, width) instantiation, e.g. Anemoi("bls12_381", 2) == the reference's AnemoiBls12_381_2_1.
+
+    Single-item methods keep the reference's names and argument meaning and run as a batch of one;
+    `*_batch` methods are the GPU-shaped forms.  `device` is a HIP ordinal or ALL_DEVICES.
+    """
+
+    def __init__(self, field, width, device=0):
+        self.field = field_id(field)
+        if lib.anemoi_field_limbs(self.field) < 0:
+            raise AnemoiError(-1)
+        if width not in (2, 4):
+            raise AnemoiError(-2)
+        self.width, self.device = width, device
+        self.limbs = lib.anemoi_field_limbs(self.field)
+        self.chunk = lib.anemoi_field_chunk_bytes(self.field)
+        self.rate = width - 1
+        self.num_columns = width // 2
+        self.num_rounds = lib.anemoi_num_rounds(self.field, width)
+
+    # ---- encoding helpers
+    def encode(self, ints):
+        """canonical Python ints -> Montgomery limb rows (via the GPU conversion kernel)."""
+        if len(ints) == 0:
+            return np.zeros((0, self.limbs), dtype=np.uint64)
+        return to_montgomery(self.field, ints_to_limbs(ints, self.limbs), self.device if self.device >= 0 else 0)
+
+    def decode(self, mont):
+        a = np.asarray(mont, dtype=np.uint64)
+        if a.size == 0:
+            return []
+        return limbs_to_ints(from_montgomery(self.field, a.reshape(-1, self.limbs),
+                                             self.device if self.device >= 0 else 0))
+
+    # ---- batched operators
+    def permutation_batch(self, states):
+        s = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, self.width, self.limbs).copy()
+        _check(lib.anemoi_permutation_batch(self.field, self.width, _p64(s), len(s), self.device))
+        return s
+
+    def sbox_layer_batch(self, states):
+        s = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, self.width, self.limbs).copy()
+        _check(lib.anemoi_sbox_layer_batch(self.field, self.width, _p64(s), len(s), self.device))
+        return s
+
+    def compress_k_batch(self, states, k):
+        s = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, self.width, self.limbs)
+        if k <= 0 or self.width % k:
+            raise AnemoiError(-3)
+        out = np.empty((len(s), self.width // k, self.limbs), dtype=np.uint64)
+        _check(lib.anemoi_jive_compress_k_batch(self.field, self.width, k, _p64(s), _p64(out), len(s), self.device))
+        return out
+
+    def compress_batch(self, states):
+        s = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, self.width, self.limbs)
+        out = np.empty((len(s), self.width // 2, self.limbs), dtype=np.uint64)
+        _check(lib.anemoi_jive_compress_batch(self.field, self.width, _p64(s), _p64(out), len(s), self.device))
+        return out
+
+    def merge_batch(self, pairs):
+        """2-1 instances: n x [left, right] digests -> n digests (anemoi_2_1/hasher.rs:87-92).
+        4-3 instances: the reference's merge (hasher.rs:131-145) puts digests[0] in BOTH rate cells
+        and returns permutation(state)[0]; reproduced here on top of permutation_batch."""
+        p = np.ascontiguousarray(pairs, dtype=np.uint64).reshape(-1, 2, self.limbs)
+        if self.width == 2:
+            out = np.empty((len(p), self.limbs), dtype=np.uint64)
+            _check(lib.anemoi_merge_batch(self.field, _p64(p), _p64(out), len(p), self.device))
+            return out
+        st = np.zeros((len(p), self.width, self.limbs), dtype=np.uint64)
+        st[:, 0] = p[:, 0]
+        st[:, 1] = p[:, 0]
+        return self.permutation_batch(st)[:, 0].copy()
+
+    def hash_field_batch(self, elems):
+        e = np.ascontiguousarray(elems, dtype=np.uint64)
+        assert e.ndim == 3 and e.shape[2] == self.limbs, "expected [n][elems_per_msg][limbs]"
+        out = np.empty((e.shape[0], self.limbs), dtype=np.uint64)
+        ptr = _p64(e) if e.size else None
+        _check(lib.anemoi_hash_field_batch(self.field, self.width, ptr, e.shape[1], e.shape[0], _p64(out),
+                                           self.device))
+        return out
+
+    def hash_batch(self, msgs):
+        m = np.ascontiguousarray(msgs, dtype=np.uint8)
+        assert m.ndim == 2, "expected [n][msg_len] bytes"
+        out = np.empty((m.shape[0], self.limbs), dtype=np.uint64)
+        ptr = _p8(m) if m.size else None
+        _check(lib.anemoi_hash_bytes_batch(self.field, self.width, ptr, m.shape[1], m.shape[0], _p64(out),
+                                           self.device))
+        return out
+
+    def merkle_root(self, leaves, depth):
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, self.limbs)
+        if len(lv) != 1 << depth:
+            raise AnemoiError(-3)
+        out = np.empty(self.limbs, dtype=np.uint64)
+        _check(lib.anemoi_merkle_root(self.field, _p64(lv), depth, _p64(out), self.device))
+        return out
+
+    # ---- the reference's single-item surface (src/traits.rs:8-33)
+    def permutation(self, state):
+        return self.permutation_batch(np.asarray(state, dtype=np.uint64).reshape(1, self.width, self.limbs))[0]
+
+    def compress(self, elems):
+        e = np.asarray(elems, dtype=np.uint64).reshape(-1, self.limbs)
+        if len(e) != self.width:  # assert!(elems.len() == STATE_WIDTH)
+            raise AnemoiError(-3)
+        return self.compress_batch(e[None])[0]
+
+    def compress_k(self, elems, k):
+        e = np.asarray(elems, dtype=np.uint64).reshape(-1, self.limbs)
+        if len(e) != self.width:
+            raise AnemoiError(-3)
+        return self.compress_k_batch(e[None], k)[0]
+
+    def hash(self, data):
+        b = np.frombuffer(bytes(data), dtype=np.uint8).reshape(1, -1)
+        return self.hash_batch(b)[0]
+
+    def hash_field(self, elems):
+        e = np.asarray(elems, dtype=np.uint64).reshape(1, -1, self.limbs)
+        return self.hash_field_batch(e)[0]
+
+    def merge(self, digests):
+        d = np.asarray(digests, dtype=np.uint64).reshape(1, 2, self.limbs)
+        return self.merge_batch(d)[0]
+
+    def digest_to_bytes(self, digest):
+        """AnemoiDigest::to_bytes (digest.rs:42-46): canonical little-endian bytes."""
+        d = np.asarray(digest, dtype=np.uint64).reshape(1, self.limbs)
+        return from_montgomery(self.field, d, self.device if self.device >= 0 else 0).tobytes()

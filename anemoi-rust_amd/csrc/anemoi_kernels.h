@@ -1,0 +1,350 @@
+// anemoi_kernels.h -- batch kernels (one item per lane) and their launchers, templated on the field.
+//
+//   k_permutation   Anemoi::permutation            src/traits.rs:370-378
+//   k_jive          Jive::compress / compress_k    src/<f>/anemoi_2_1/hasher.rs:96-110, anemoi_4_3/hasher.rs:148-179
+//   k_sponge        Sponge::hash / hash_field      src/<f>/anemoi_2_1/hasher.rs:18-85, anemoi_4_3/hasher.rs:19-129
+//   k_mont_convert  canonical <-> Montgomery (arkworks into_bigint / from_bigint)
+//
+// Data layout in HBM: array-of-states, each state `W` elements of N 32-bit limbs (= the reference's
+// `&[Felt]` bytes).  A workgroup's states are contiguous, so it moves them with 16-byte-per-lane
+// coalesced loads/stores and transposes through LDS into one-state-per-lane registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "anemoi_perm.h"
+
+namespace anemoi {
+
+constexpr int kBlock = 64;  // one wavefront per workgroup: the LDS window table is lane-private
+
+template <int N>
+struct KernelCfg {
+  static constexpr int WIN = 4;  // sliding-window bits -> 8 odd powers per lane in LDS
+};
+
+template <int N, int WIN>
+constexpr size_t lds_table_bytes() {
+  return size_t(1 << (WIN - 1)) * N * 4 * kBlock;
+}
+
+template <int N, int WIN, int W>
+constexpr size_t lds_bytes() {
+  size_t tab = lds_table_bytes<N, WIN>(), stage = size_t(W) * N * 4 * kBlock;
+  return tab > stage ? tab : stage;
+}
+
+// ---- coalesced block I/O through LDS -------------------------------------------------------------
+// The block owns items [blk0, blk0 + cnt) of `per_item` uint4 each, contiguous in global memory.
+template <int PER_ITEM>
+__device__ __forceinline__ void block_load(uint4* lds, const uint4* __restrict__ g, size_t blk0, int cnt) {
+  const uint4* src = g + blk0 * PER_ITEM;
+  const int total = cnt * PER_ITEM;
+#pragma unroll
+  for (int i = 0; i < PER_ITEM; i++) {
+    int idx = i * kBlock + threadIdx.x;
+    if (idx < total) lds[idx] = src[idx];
+  }
+  __syncthreads();
+}
+
+template <int PER_ITEM>
+__device__ __forceinline__ void block_store(uint4* lds, uint4* __restrict__ g, size_t blk0, int cnt) {
+  __syncthreads();
+  uint4* dst = g + blk0 * PER_ITEM;
+  const int total = cnt * PER_ITEM;
+#pragma unroll
+  for (int i = 0; i < PER_ITEM; i++) {
+    int idx = i * kBlock + threadIdx.x;
+    if (idx < total) dst[idx] = lds[idx];
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void lds_get(const uint4* lds, int slot, Fe<N>& v) {
+#pragma unroll
+  for (int q = 0; q < N / 4; q++) {
+    uint4 t = lds[slot * (N / 4) + q];
+    v.l[4 * q] = t.x;
+    v.l[4 * q + 1] = t.y;
+    v.l[4 * q + 2] = t.z;
+    v.l[4 * q + 3] = t.w;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void lds_put(uint4* lds, int slot, const Fe<N>& v) {
+#pragma unroll
+  for (int q = 0; q < N / 4; q++)
+    lds[slot * (N / 4) + q] = make_uint4(v.l[4 * q], v.l[4 * q + 1], v.l[4 * q + 2], v.l[4 * q + 3]);
+}
+
+template <int N>
+__device__ __forceinline__ LdsTable<N> make_table(uint4* lds) {
+  LdsTable<N> t;
+  t.base = lds + threadIdx.x;
+  t.stride = kBlock;
+  return t;
+}
+
+// ---- kernels -------------------------------------------------------------------------------------
+
+// SBOX_ONLY: apply just Anemoi::sbox_layer (src/traits.rs:326-358) -- the unit the reference's
+// test_sbox KATs pin (src/<f>/anemoi_x/mod.rs:68).
+template <int FIELD, int W, bool SBOX_ONLY>
+__global__ __launch_bounds__(kBlock) void k_permutation(uint4* __restrict__ states, size_t n, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  constexpr int N = F::N, WIN = KernelCfg<N>::WIN, PER = W * N / 4;
+  extern __shared__ uint4 lds[];
+  const size_t blk0 = size_t(blockIdx.x) * kBlock;
+  const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
+  block_load<PER>(lds, states, blk0, cnt);
+  Fe<N> st[W];
+#pragma unroll
+  for (int i = 0; i < W; i++) lds_get<N>(lds, threadIdx.x * W + i, st[i]);
+  __syncthreads();
+  if (SBOX_ONLY) {
+    flystel<F, WIN>(st[0], st[W / 2], pc, make_table<N>(lds));
+    if (W == 4) flystel<F, WIN>(st[1], st[3], pc, make_table<N>(lds));
+  } else {
+    permutation<F, W, WIN>(st, pc, make_table<N>(lds));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < W; i++) lds_put<N>(lds, threadIdx.x * W + i, st[i]);
+  block_store<PER>(lds, states, blk0, cnt);
+}
+
+// out[i] = sum_{j<k} in[i + c*j] + perm(in)[i + c*j], c = W/k  (k = 2: c = W/2 outputs; k = 4: 1 output)
+template <int FIELD, int W, int K>
+__global__ __launch_bounds__(kBlock) void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n,
+                                                 PermConsts pc) {
+  using F = FieldC<FIELD>;
+  constexpr int N = F::N, WIN = KernelCfg<N>::WIN, PER = W * N / 4, C = W / K;
+  extern __shared__ uint4 lds[];
+  const size_t blk0 = size_t(blockIdx.x) * kBlock;
+  const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
+  block_load<PER>(lds, in, blk0, cnt);
+  Fe<N> st[W], sum[C];
+#pragma unroll
+  for (int i = 0; i < W; i++) lds_get<N>(lds, threadIdx.x * W + i, st[i]);
+  __syncthreads();
+  permutation<F, W, WIN>(st, pc, make_table<N>(lds));
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    sum[i] = st[i];
+#pragma unroll
+    for (int j = 1; j < K; j++) fe_add<F>(sum[i], sum[i], st[i + C * j]);
+  }
+  // Jive feed-forward: the inputs are fetched again (L2-resident, 96 B per item) instead of
+  // being held in 12-24 VGPRs across the whole permutation
+  __syncthreads();
+  block_load<PER>(lds, in, blk0, cnt);
+#pragma unroll
+  for (int i = 0; i < W; i++) lds_get<N>(lds, threadIdx.x * W + i, st[i]);
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+#pragma unroll
+    for (int j = 0; j < K; j++) fe_add<F>(sum[i], sum[i], st[i + C * j]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < C; i++) lds_put<N>(lds, threadIdx.x * C + i, sum[i]);
+  block_store<C * N / 4>(lds, out, blk0, cnt);
+}
+
+// One chunk of a byte message -> Montgomery element (from_le_bytes_mod_order + the reference's
+// padding rule: a SHORT last chunk gets a 0x01 byte appended; hasher.rs:36-57).
+template <class F>
+__device__ __forceinline__ void chunk_to_fe(Fe<F::N>& e, const uint8_t* __restrict__ p, int len) {
+  constexpr int N = F::N;
+  Fe<N> v, r2;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int pos = 4 * i + b;
+      uint32_t byte = 0;
+      if (pos < F::kChunk) {
+        if (pos < len) byte = p[pos];
+        else if (pos == len) byte = 1;  // only reachable when len < kChunk
+      }
+      w |= byte << (8 * b);
+    }
+    v.l[i] = w;
+    r2.l[i] = F::R2[i];
+  }
+  // value < 2^(8*kChunk+1) < p: already reduced; enter Montgomery form
+  mont_mul<F, true>(e, v, r2);
+}
+
+// Sponge over `num` elements per message (BYTES: taken from msg_len-byte messages; else Montgomery
+// elements).  Unified rule (== both hasher.rs variants): absorb into state[i]; permute when
+// i == RATE; if num % RATE != 0 absorb a final 1 and permute; digest = state[0].
+template <int FIELD, int W, bool BYTES>
+__global__ __launch_bounds__(kBlock) void k_sponge(const void* __restrict__ src, size_t per_msg, size_t n,
+                                                   uint4* __restrict__ out, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  constexpr int N = F::N, WIN = KernelCfg<N>::WIN, RATE = W - 1;
+  extern __shared__ uint4 lds[];
+  const size_t blk0 = size_t(blockIdx.x) * kBlock;
+  const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
+  const size_t item = blk0 + (threadIdx.x < cnt ? threadIdx.x : 0);  // idle lanes redo item blk0
+  const size_t num = BYTES ? (per_msg + F::kChunk - 1) / F::kChunk : per_msg;
+  const size_t total = num + (num % RATE == 0 ? 0 : 1);
+  const uint8_t* msg = (const uint8_t*)src + (BYTES ? item * per_msg : item * per_msg * N * 4);
+  Fe<N> st[W];
+#pragma unroll
+  for (int i = 0; i < W; i++)
+#pragma unroll
+    for (int l = 0; l < N; l++) st[i].l[l] = 0;
+  int pos = 0;
+  const LdsTable<N> tab = make_table<N>(lds);
+#pragma nounroll
+  for (size_t e = 0; e < total; e++) {
+    Fe<N> el;
+    if (e < num) {
+      if (BYTES) {
+        const size_t off = e * F::kChunk;
+        const size_t left = per_msg - off;
+        chunk_to_fe<F>(el, msg + off, left < size_t(F::kChunk) ? int(left) : F::kChunk);
+      } else {
+        const uint32_t* w = (const uint32_t*)msg + e * N;
+#pragma unroll
+        for (int l = 0; l < N; l++) el.l[l] = w[l];
+      }
+    } else {
+#pragma unroll
+      for (int l = 0; l < N; l++) el.l[l] = F::One[l];
+    }
+    // pos is wave-uniform (every message has the same length)
+    if (RATE == 1 || pos == 0) fe_add<F>(st[0], st[0], el);
+    else if (pos == 1) fe_add<F>(st[1], st[1], el);
+    else fe_add<F>(st[RATE - 1], st[RATE - 1], el);
+    pos++;
+    if (pos == RATE || e == total - 1) {
+      permutation<F, W, WIN>(st, pc, tab);
+      pos = 0;
+    }
+  }
+  __syncthreads();
+  lds_put<N>(lds, threadIdx.x, st[0]);
+  block_store<N / 4>(lds, out, blk0, cnt);
+}
+
+// to = true: canonical -> Montgomery (x * R^2 / R); to = false: Montgomery -> canonical (x * 1 / R)
+template <int FIELD>
+__global__ __launch_bounds__(kBlock) void k_mont_convert(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                         size_t count, int to) {
+  using F = FieldC<FIELD>;
+  constexpr int N = F::N;
+  extern __shared__ uint4 lds[];
+  const size_t blk0 = size_t(blockIdx.x) * kBlock;
+  const int cnt = count - blk0 < size_t(kBlock) ? int(count - blk0) : kBlock;
+  block_load<N / 4>(lds, in, blk0, cnt);
+  Fe<N> v, k;
+  lds_get<N>(lds, threadIdx.x, v);
+#pragma unroll
+  for (int i = 0; i < N; i++) k.l[i] = to ? F::R2[i] : (i == 0 ? 1u : 0u);
+  mont_mul<F, true>(v, v, k);
+  __syncthreads();
+  lds_put<N>(lds, threadIdx.x, v);
+  block_store<N / 4>(lds, out, blk0, cnt);
+}
+
+// ---- launchers (one set per field translation unit) ------------------------------------------------
+
+struct HostConsts {  // what the context uploads for one (field, width)
+  std::vector<uint32_t> ark_c, ark_d;
+  std::vector<uint8_t> sched;
+  int steps, first;
+};
+
+struct FieldOps {
+  int limbs64, chunk, rounds21, rounds43;
+  const char* name;
+  void (*host_consts)(int width, HostConsts* out);
+  hipError_t (*permutation)(int width, int sbox_only, void* d_states, size_t n, PermConsts pc, hipStream_t s);
+  hipError_t (*jive)(int width, int k, const void* d_in, void* d_out, size_t n, PermConsts pc, hipStream_t s);
+  hipError_t (*sponge)(int width, int bytes, const void* d_src, size_t per_msg, size_t n, void* d_out, PermConsts pc,
+                       hipStream_t s);
+  hipError_t (*mont_convert)(int to, const void* d_in, void* d_out, size_t count, hipStream_t s);
+};
+
+const FieldOps* field_ops(int field);  // capi.hip
+
+inline unsigned grid_for(size_t n) { return unsigned((n + kBlock - 1) / kBlock); }
+
+template <int FIELD>
+struct Launch {
+  using F = FieldC<FIELD>;
+  static constexpr int N = F::N, WIN = KernelCfg<N>::WIN;
+
+  static void host_consts(int width, HostConsts* hc) {
+    const uint32_t* c = width == 2 ? F::ArkC21 : F::ArkC43;
+    const uint32_t* d = width == 2 ? F::ArkD21 : F::ArkD43;
+    const int cnt = (width == 2 ? F::kRounds21 : 2 * F::kRounds43) * N;
+    hc->ark_c.assign(c, c + cnt);
+    hc->ark_d.assign(d, d + cnt);
+    static_assert(WIN == 4, "schedule selection below assumes the 4-bit window");
+    hc->sched.assign(F::kW4Sched, F::kW4Sched + 2 * F::kW4Steps);
+    hc->steps = F::kW4Steps;
+    hc->first = F::kW4First;
+  }
+
+  static hipError_t permutation(int width, int sbox_only, void* d, size_t n, PermConsts pc, hipStream_t s) {
+    if (!n) return hipSuccess;
+    if (width == 2 && !sbox_only)
+      k_permutation<FIELD, 2, false><<<grid_for(n), kBlock, lds_bytes<N, WIN, 2>(), s>>>((uint4*)d, n, pc);
+    else if (width == 2)
+      k_permutation<FIELD, 2, true><<<grid_for(n), kBlock, lds_bytes<N, WIN, 2>(), s>>>((uint4*)d, n, pc);
+    else if (!sbox_only)
+      k_permutation<FIELD, 4, false><<<grid_for(n), kBlock, lds_bytes<N, WIN, 4>(), s>>>((uint4*)d, n, pc);
+    else
+      k_permutation<FIELD, 4, true><<<grid_for(n), kBlock, lds_bytes<N, WIN, 4>(), s>>>((uint4*)d, n, pc);
+    return hipGetLastError();
+  }
+
+  static hipError_t jive(int width, int k, const void* in, void* out, size_t n, PermConsts pc, hipStream_t s) {
+    if (!n) return hipSuccess;
+    if (width == 2)
+      k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, lds_bytes<N, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+    else if (k == 2)
+      k_jive<FIELD, 4, 2><<<grid_for(n), kBlock, lds_bytes<N, WIN, 4>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+    else
+      k_jive<FIELD, 4, 4><<<grid_for(n), kBlock, lds_bytes<N, WIN, 4>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+    return hipGetLastError();
+  }
+
+  static hipError_t sponge(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
+                           hipStream_t s) {
+    if (!n) return hipSuccess;
+    const size_t l = lds_bytes<N, WIN, 1>();
+    if (width == 2 && bytes)
+      k_sponge<FIELD, 2, true><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc);
+    else if (width == 2)
+      k_sponge<FIELD, 2, false><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc);
+    else if (bytes)
+      k_sponge<FIELD, 4, true><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc);
+    else
+      k_sponge<FIELD, 4, false><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc);
+    return hipGetLastError();
+  }
+
+  static hipError_t mont_convert(int to, const void* in, void* out, size_t count, hipStream_t s) {
+    if (!count) return hipSuccess;
+    k_mont_convert<FIELD><<<grid_for(count), kBlock, size_t(N) * 4 * kBlock, s>>>((const uint4*)in, (uint4*)out, count, to);
+    return hipGetLastError();
+  }
+
+  static const FieldOps* ops() {
+    static const FieldOps o{F::L64,      F::kChunk,   F::kRounds21, F::kRounds43, F::kName,
+                            host_consts, permutation, jive,         sponge,       mont_convert};
+    return &o;
+  }
+};
+
+}  // namespace anemoi

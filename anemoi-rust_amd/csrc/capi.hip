@@ -1,0 +1,492 @@
+// capi.hip -- the C-ABI of libanemoi_mi355x.so (declared in include/anemoi_mi355x.h).
+//
+// Host side only: argument checks (the reference's assert!s -> error codes), the lazily created
+// per-device constant tables, H2D/D2H staging for the host-pointer entry points, contiguous-range
+// sharding over GPUs (no collective: items are independent) and the level-by-level
+// Merkle driver.  All arithmetic runs in the HIP kernels of anemoi_kernels.h; there is no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/anemoi_mi355x.h"
+#include "anemoi_kernels.h"
+
+namespace anemoi {
+const FieldOps *field_ops_0(), *field_ops_1(), *field_ops_2(), *field_ops_3(), *field_ops_4(), *field_ops_5(),
+    *field_ops_6();
+
+const FieldOps* field_ops(int field) {
+  static const FieldOps* const table[kNumFields] = {field_ops_0(), field_ops_1(), field_ops_2(), field_ops_3(),
+                                                    field_ops_4(), field_ops_5(), field_ops_6()};
+  return field >= 0 && field < kNumFields ? table[field] : nullptr;
+}
+}  // namespace anemoi
+
+using anemoi::FieldOps;
+using anemoi::PermConsts;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail_hip(hipError_t e, const char* what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return ANEMOI_ERR_DEVICE;
+}
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t e_ = (expr);                            \
+    if (e_ != hipSuccess) return fail_hip(e_, #expr);  \
+  } while (0)
+
+constexpr int kMaxDevices = 64;
+
+struct DeviceCtx {
+  std::mutex mu;
+  bool ready[anemoi::kNumFields][2] = {};
+  PermConsts pc[anemoi::kNumFields][2] = {};
+};
+DeviceCtx g_ctx[kMaxDevices];
+
+// Constant tables for (current device, field, width); uploaded once.
+int get_consts(int field, int width, PermConsts* out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return ANEMOI_ERR_DEVICE;
+  DeviceCtx& c = g_ctx[dev];
+  const int wi = width == 2 ? 0 : 1;
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (!c.ready[field][wi]) {
+    anemoi::HostConsts hc;
+    anemoi::field_ops(field)->host_consts(width, &hc);
+    const size_t ab = hc.ark_c.size() * sizeof(uint32_t), sb = hc.sched.size();
+    char* blob = nullptr;
+    HIP_TRY(hipMalloc((void**)&blob, 2 * ab + sb));
+    HIP_TRY(hipMemcpy(blob, hc.ark_c.data(), ab, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(blob + ab, hc.ark_d.data(), ab, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(blob + 2 * ab, hc.sched.data(), sb, hipMemcpyHostToDevice));
+    PermConsts pc;
+    pc.ark_c = (const uint32_t*)blob;
+    pc.ark_d = (const uint32_t*)(blob + ab);
+    pc.sched = (const uint8_t*)(blob + 2 * ab);
+    pc.steps = hc.steps;
+    pc.first = hc.first;
+    c.pc[field][wi] = pc;
+    c.ready[field][wi] = true;
+  }
+  *out = c.pc[field][wi];
+  return ANEMOI_OK;
+}
+
+int check_instance(int field, int width) {
+  if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
+  if (width != 2 && width != 4) return ANEMOI_ERR_WIDTH;
+  return ANEMOI_OK;
+}
+
+// the reference's compress_k asserts (anemoi_2_1/hasher.rs:107; anemoi_4_3/hasher.rs:163-165)
+int check_k(int width, int k) {
+  if (width == 2) return k == 2 ? ANEMOI_OK : ANEMOI_ERR_ARG;
+  return (k == 2 || k == 4) ? ANEMOI_OK : ANEMOI_ERR_ARG;
+}
+
+size_t elem_bytes(int field) { return size_t(anemoi::field_ops(field)->limbs64) * 8; }
+
+struct DeviceGuard {  // restores the caller's current device
+  int prev = -1;
+  DeviceGuard() { (void)hipGetDevice(&prev); }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+      g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+      return ANEMOI_ERR_ALLOC;
+    }
+    return ANEMOI_OK;
+  }
+};
+
+// Runs `body(first, count)` on one device, or on contiguous ranges over all devices (one host
+// thread per GPU).  body must be thread-safe and set its own device.
+template <class Body>
+int for_devices(int device, size_t n, Body body) {
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) {
+    g_last_error = "no HIP device";
+    return ANEMOI_ERR_DEVICE;
+  }
+  if (device != ANEMOI_ALL_DEVICES) {
+    if (device < 0 || device >= ndev || device >= kMaxDevices) {
+      g_last_error = "device ordinal out of range";
+      return ANEMOI_ERR_DEVICE;
+    }
+    return body(device, size_t(0), n);
+  }
+  if (ndev > kMaxDevices) ndev = kMaxDevices;
+  if (ndev == 1 || n < size_t(ndev)) return body(0, size_t(0), n);
+  std::vector<int> rc(ndev, ANEMOI_OK);
+  std::vector<std::string> err(ndev);
+  std::vector<std::thread> th;
+  for (int d = 0; d < ndev; d++) {
+    const size_t b = n * size_t(d) / size_t(ndev), e = n * size_t(d + 1) / size_t(ndev);
+    th.emplace_back([&, d, b, e] {
+      rc[d] = body(d, b, e - b);
+      if (rc[d] != ANEMOI_OK) err[d] = g_last_error;
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int d = 0; d < ndev; d++)
+    if (rc[d] != ANEMOI_OK) {
+      g_last_error = err[d];
+      return rc[d];
+    }
+  return ANEMOI_OK;
+}
+
+// Generic host-pointer batch: copy `in_bytes_per_item` per item in, run `launch`, copy out.
+template <class LaunchFn>
+int host_batch(int device, size_t n, const void* in, size_t in_per_item, void* out, size_t out_per_item,
+               LaunchFn launch) {
+  if (n == 0) return ANEMOI_OK;
+  return for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
+    if (count == 0) return ANEMOI_OK;
+    DeviceGuard guard;
+    HIP_TRY(hipSetDevice(dev));
+    DevBuf din, dout;
+    int rc = din.alloc(count * in_per_item);
+    if (rc) return rc;
+    if (out != in) {
+      rc = dout.alloc(count * out_per_item);
+      if (rc) return rc;
+    }
+    void* o = out != in ? dout.p : din.p;
+    HIP_TRY(hipMemcpy(din.p, (const char*)in + first * in_per_item, count * in_per_item, hipMemcpyHostToDevice));
+    rc = launch(din.p, o, count);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy((char*)out + first * out_per_item, o, count * out_per_item, hipMemcpyDeviceToHost));
+    return ANEMOI_OK;
+  });
+}
+
+int merkle_levels_dev(int field, const void* d_leaves, unsigned depth, void* d_scratch, void* d_root,
+                      hipStream_t s) {
+  const FieldOps* ops = anemoi::field_ops(field);
+  const size_t eb = elem_bytes(field);
+  if (depth == 0) {
+    HIP_TRY(hipMemcpyAsync(d_root, d_leaves, eb, hipMemcpyDeviceToDevice, s));
+    return ANEMOI_OK;
+  }
+  PermConsts pc;
+  int rc = get_consts(field, 2, &pc);
+  if (rc) return rc;
+  // ping-pong halves of the scratch: level l (n = 2^(depth-1-l) nodes) reads `src`, writes `dst`
+  char* a = (char*)d_scratch;
+  char* b = a + (size_t(1) << (depth - 1)) * eb;
+  const void* src = d_leaves;
+  for (unsigned l = 0; l < depth; l++) {
+    const size_t n = size_t(1) << (depth - 1 - l);
+    void* dst = n == 1 ? d_root : (void*)((l & 1) ? b : a);
+    HIP_TRY(ops->jive(2, 2, src, dst, n, pc, s));
+    src = dst;
+  }
+  return ANEMOI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int anemoi_abi_version(void) { return 1; }
+
+int anemoi_device_count(void) {
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  return n;
+}
+
+const char* anemoi_strerror(int code) {
+  switch (code) {
+    case ANEMOI_OK: return "ok";
+    case ANEMOI_ERR_FIELD: return "unknown field id";
+    case ANEMOI_ERR_WIDTH: return "state width must be 2 or 4";
+    case ANEMOI_ERR_ARG: return "invalid argument (null pointer, unsupported k, or size out of range)";
+    case ANEMOI_ERR_DEVICE: return "HIP device error";
+    case ANEMOI_ERR_ALLOC: return "allocation failed";
+    default: return "unknown error code";
+  }
+}
+
+const char* anemoi_last_error(void) { return g_last_error.c_str(); }
+
+int anemoi_field_id(const char* name) {
+  if (!name) return ANEMOI_ERR_ARG;
+  for (int f = 0; f < anemoi::kNumFields; f++)
+    if (!strcmp(name, anemoi::field_ops(f)->name)) return f;
+  return ANEMOI_ERR_FIELD;
+}
+
+const char* anemoi_field_name(int field) {
+  const FieldOps* o = anemoi::field_ops(field);
+  return o ? o->name : nullptr;
+}
+
+int anemoi_field_limbs(int field) {
+  const FieldOps* o = anemoi::field_ops(field);
+  return o ? o->limbs64 : ANEMOI_ERR_FIELD;
+}
+
+int anemoi_field_chunk_bytes(int field) {
+  const FieldOps* o = anemoi::field_ops(field);
+  return o ? o->chunk : ANEMOI_ERR_FIELD;
+}
+
+int anemoi_num_rounds(int field, int width) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  const FieldOps* o = anemoi::field_ops(field);
+  return width == 2 ? o->rounds21 : o->rounds43;
+}
+
+/* ---- device-pointer API ---- */
+
+int anemoi_permutation_dev(int field, int width, void* d_states, size_t n, void* stream) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && !d_states) return ANEMOI_ERR_ARG;
+  PermConsts pc;
+  if ((rc = get_consts(field, width, &pc))) return rc;
+  HIP_TRY(anemoi::field_ops(field)->permutation(width, 0, d_states, n, pc, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+int anemoi_sbox_layer_dev(int field, int width, void* d_states, size_t n, void* stream) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && !d_states) return ANEMOI_ERR_ARG;
+  PermConsts pc;
+  if ((rc = get_consts(field, width, &pc))) return rc;
+  HIP_TRY(anemoi::field_ops(field)->permutation(width, 1, d_states, n, pc, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+int anemoi_jive_compress_k_dev(int field, int width, int k, const void* d_in, void* d_out, size_t n, void* stream) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if ((rc = check_k(width, k))) return rc;
+  if (n && (!d_in || !d_out)) return ANEMOI_ERR_ARG;
+  PermConsts pc;
+  if ((rc = get_consts(field, width, &pc))) return rc;
+  HIP_TRY(anemoi::field_ops(field)->jive(width, k, d_in, d_out, n, pc, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+int anemoi_hash_field_dev(int field, int width, const void* d_elems, size_t elems_per_msg, size_t n, void* d_out,
+                          void* stream) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && (!d_out || (elems_per_msg && !d_elems))) return ANEMOI_ERR_ARG;
+  PermConsts pc;
+  if ((rc = get_consts(field, width, &pc))) return rc;
+  HIP_TRY(anemoi::field_ops(field)->sponge(width, 0, d_elems, elems_per_msg, n, d_out, pc, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+int anemoi_hash_bytes_dev(int field, int width, const void* d_msgs, size_t msg_len, size_t n, void* d_out,
+                          void* stream) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && (!d_out || (msg_len && !d_msgs))) return ANEMOI_ERR_ARG;
+  PermConsts pc;
+  if ((rc = get_consts(field, width, &pc))) return rc;
+  HIP_TRY(anemoi::field_ops(field)->sponge(width, 1, d_msgs, msg_len, n, d_out, pc, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+int anemoi_merkle_root_dev(int field, const void* d_leaves, unsigned depth, void* d_scratch, void* d_root,
+                           void* stream) {
+  int rc = check_instance(field, 2);
+  if (rc) return rc;
+  if (!d_leaves || !d_root || depth > 30 || (depth && !d_scratch)) return ANEMOI_ERR_ARG;
+  return merkle_levels_dev(field, d_leaves, depth, d_scratch, d_root, (hipStream_t)stream);
+}
+
+int anemoi_to_montgomery_dev(int field, const void* d_in, void* d_out, size_t count, void* stream) {
+  if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
+  if (count && (!d_in || !d_out)) return ANEMOI_ERR_ARG;
+  HIP_TRY(anemoi::field_ops(field)->mont_convert(1, d_in, d_out, count, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+int anemoi_from_montgomery_dev(int field, const void* d_in, void* d_out, size_t count, void* stream) {
+  if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
+  if (count && (!d_in || !d_out)) return ANEMOI_ERR_ARG;
+  HIP_TRY(anemoi::field_ops(field)->mont_convert(0, d_in, d_out, count, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+/* ---- host-pointer API ---- */
+
+int anemoi_permutation_batch(int field, int width, uint64_t* states, size_t n, int device) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && !states) return ANEMOI_ERR_ARG;
+  const size_t per = elem_bytes(field) * width;
+  return host_batch(device, n, states, per, states, per, [&](void* in, void*, size_t cnt) {
+    return anemoi_permutation_dev(field, width, in, cnt, nullptr);
+  });
+}
+
+int anemoi_sbox_layer_batch(int field, int width, uint64_t* states, size_t n, int device) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && !states) return ANEMOI_ERR_ARG;
+  const size_t per = elem_bytes(field) * width;
+  return host_batch(device, n, states, per, states, per, [&](void* in, void*, size_t cnt) {
+    return anemoi_sbox_layer_dev(field, width, in, cnt, nullptr);
+  });
+}
+
+int anemoi_jive_compress_k_batch(int field, int width, int k, const uint64_t* in, uint64_t* out, size_t n,
+                                 int device) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if ((rc = check_k(width, k))) return rc;
+  if (n && (!in || !out)) return ANEMOI_ERR_ARG;
+  if ((const void*)in == (void*)out) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field);
+  return host_batch(device, n, in, eb * width, out, eb * (width / k), [&](void* i, void* o, size_t cnt) {
+    return anemoi_jive_compress_k_dev(field, width, k, i, o, cnt, nullptr);
+  });
+}
+
+int anemoi_jive_compress_batch(int field, int width, const uint64_t* in, uint64_t* out, size_t n, int device) {
+  return anemoi_jive_compress_k_batch(field, width, 2, in, out, n, device);
+}
+
+int anemoi_merge_batch(int field, const uint64_t* pairs, uint64_t* out, size_t n, int device) {
+  return anemoi_jive_compress_k_batch(field, 2, 2, pairs, out, n, device);
+}
+
+int anemoi_hash_field_batch(int field, int width, const uint64_t* elems, size_t elems_per_msg, size_t n,
+                            uint64_t* out, int device) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && (!out || (elems_per_msg && !elems))) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field);
+  static const uint64_t dummy[2] = {0, 0};
+  return host_batch(device, n, elems ? (const void*)elems : (const void*)dummy, eb * elems_per_msg, out, eb,
+                    [&](void* i, void* o, size_t cnt) {
+                      return anemoi_hash_field_dev(field, width, i, elems_per_msg, cnt, o, nullptr);
+                    });
+}
+
+int anemoi_hash_bytes_batch(int field, int width, const uint8_t* msgs, size_t msg_len, size_t n, uint64_t* out,
+                            int device) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && (!out || (msg_len && !msgs))) return ANEMOI_ERR_ARG;
+  static const uint64_t dummy[2] = {0, 0};
+  return host_batch(device, n, msgs ? (const void*)msgs : (const void*)dummy, msg_len, out, elem_bytes(field),
+                    [&](void* i, void* o, size_t cnt) {
+                      return anemoi_hash_bytes_dev(field, width, i, msg_len, cnt, o, nullptr);
+                    });
+}
+
+int anemoi_to_montgomery(int field, const uint64_t* in, uint64_t* out, size_t count, int device) {
+  if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
+  if (count && (!in || !out)) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field);
+  return host_batch(device, count, in, eb, out, eb, [&](void* i, void* o, size_t cnt) {
+    return anemoi_to_montgomery_dev(field, i, o, cnt, nullptr);
+  });
+}
+
+int anemoi_from_montgomery(int field, const uint64_t* in, uint64_t* out, size_t count, int device) {
+  if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
+  if (count && (!in || !out)) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field);
+  return host_batch(device, count, in, eb, out, eb, [&](void* i, void* o, size_t cnt) {
+    return anemoi_from_montgomery_dev(field, i, o, cnt, nullptr);
+  });
+}
+
+int anemoi_merkle_root(int field, const uint64_t* leaves, unsigned depth, uint64_t* root, int device) {
+  int rc = check_instance(field, 2);
+  if (rc) return rc;
+  if (!leaves || !root || depth > 30) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) {
+    g_last_error = "no HIP device";
+    return ANEMOI_ERR_DEVICE;
+  }
+  // number of subtrees: a power of two, at most the GPU count and at most 2^depth
+  unsigned sub_log = 0;
+  if (device == ANEMOI_ALL_DEVICES)
+    while ((2u << sub_log) <= unsigned(ndev) && sub_log + 1 <= depth) sub_log++;
+  const unsigned nsub = 1u << sub_log, sub_depth = depth - sub_log;
+  std::vector<uint64_t> tops(size_t(nsub) * (eb / 8));
+  // each subtree is one "item" of the sharded loop: subtree i runs on device i (or `device`)
+  auto subtree = [&](int dev, size_t idx) -> int {
+    DeviceGuard guard;
+    HIP_TRY(hipSetDevice(dev));
+    const size_t nleaf = size_t(1) << sub_depth;
+    DevBuf dl, ds, dr;
+    int r = dl.alloc(nleaf * eb);
+    if (!r) r = ds.alloc(nleaf * eb);
+    if (!r) r = dr.alloc(eb);
+    if (r) return r;
+    HIP_TRY(hipMemcpy(dl.p, (const char*)leaves + idx * nleaf * eb, nleaf * eb, hipMemcpyHostToDevice));
+    r = merkle_levels_dev(field, dl.p, sub_depth, ds.p, dr.p, nullptr);
+    if (r) return r;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy((char*)tops.data() + idx * eb, dr.p, eb, hipMemcpyDeviceToHost));
+    return ANEMOI_OK;
+  };
+  if (nsub == 1) {
+    const int dev = device == ANEMOI_ALL_DEVICES ? 0 : device;
+    if (dev < 0 || dev >= ndev) {
+      g_last_error = "device ordinal out of range";
+      return ANEMOI_ERR_DEVICE;
+    }
+    if ((rc = subtree(dev, 0))) return rc;
+    memcpy(root, tops.data(), eb);
+    return ANEMOI_OK;
+  }
+  std::vector<int> rcs(nsub, ANEMOI_OK);
+  std::vector<std::string> errs(nsub);
+  std::vector<std::thread> th;
+  for (unsigned i = 0; i < nsub; i++)
+    th.emplace_back([&, i] {
+      rcs[i] = subtree(int(i), i);
+      if (rcs[i]) errs[i] = g_last_error;
+    });
+  for (auto& t : th) t.join();
+  for (unsigned i = 0; i < nsub; i++)
+    if (rcs[i]) {
+      g_last_error = errs[i];
+      return rcs[i];
+    }
+  // the only cross-GPU data: nsub subtree roots (<= 8 x 48 B), finished on device 0
+  return anemoi_merkle_root(field, tops.data(), sub_log, root, 0);
+}
+
+}  // extern "C"

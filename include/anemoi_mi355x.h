@@ -1,0 +1,134 @@
+/*
+ * anemoi_mi355x.h -- C-ABI of libanemoi_mi355x.so: batched Anemoi permutation, Jive compression and
+ * sponge hashing on AMD Instinct MI355X (gfx950), hand-written HIP kernels.
+ *
+ * This is the drop-in boundary for the reference crate anemoi-hash/anemoi-rust: the reference has
+ * no FFI and no batch entry point (every function processes ONE state, `#![deny(unsafe_code)]`,
+ * src/lib.rs:13), so each entry point below is the batched form of one reference function and is
+ * defined to equal, element by element, that function applied to each item.  A Rust `-sys` shim
+ * binds these symbols (INTEGRATION.md shows it) underneath the unchanged `Sponge` / `Jive` traits
+ * (src/traits.rs:8-33).
+ *
+ * ELEMENT ENCODING (all `uint64_t*` element buffers): one field element = L little-endian u64
+ * limbs (L = anemoi_field_limbs(field): 6 for bls12_381 / bls12_377, 4 otherwise), in MONTGOMERY
+ * form with R = 2^(64 L), fully reduced (< p).  That is byte-for-byte the in-memory form of the
+ * reference's `Felt` = arkworks `Fp<MontBackend<_, L>, L>` (src/<field>/mod.rs:1-3), so a Rust
+ * caller passes `slice.as_ptr()` unchanged.  Non-Rust callers convert canonical integers with
+ * anemoi_to_montgomery / anemoi_from_montgomery.  Inputs must be fully reduced; outputs always are.
+ *
+ * OWNERSHIP / THREADING: the caller allocates and owns every buffer.  The library owns only its
+ * per-device constant tables and scratch, created lazily under a mutex.  Every function is
+ * re-entrant and may be called from any thread.  No function aborts or throws: errors are negative
+ * return codes (the reference's `assert!` panics, e.g. hasher.rs:97,107, map to ANEMOI_ERR_ARG and
+ * are re-raised as panics by the Rust shim).
+ *
+ * DEVICES: host-pointer functions take `device` = a HIP ordinal, or ANEMOI_ALL_DEVICES to split
+ * the batch into contiguous ranges over every visible GPU (no collective: items are independent).
+ * `_dev` functions take pointers already resident in the current device's HBM plus a hipStream_t
+ * (passed as void*, NULL = default stream), enqueue asynchronously and never synchronise.
+ */
+#ifndef ANEMOI_MI355X_H
+#define ANEMOI_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* field ids = the reference's module names (src/lib.rs:27-64) */
+enum {
+  ANEMOI_BLS12_381 = 0,       /* ark_bls12_381::Fq, 6 limbs, 47-byte chunks */
+  ANEMOI_BLS12_377 = 1,       /* ark_bls12_377::Fq, 6 limbs, 47-byte chunks */
+  ANEMOI_BN_254 = 2,          /* ark_bn254::Fq,     4 limbs, 31-byte chunks */
+  ANEMOI_ED_ON_BLS12_377 = 3, /* ark_bls12_377::Fr, 4 limbs, alpha = 11, g = 22 */
+  ANEMOI_JUBJUB = 4,          /* ark_bls12_381::Fr, 4 limbs */
+  ANEMOI_PALLAS = 5,          /* ark_pallas::Fq,    4 limbs */
+  ANEMOI_VESTA = 6,           /* ark_pallas::Fr,    4 limbs */
+  ANEMOI_NUM_FIELDS = 7
+};
+
+/* width = STATE_WIDTH of the instance: 2 (Anemoi-2-1, rate 1) or 4 (Anemoi-4-3, rate 3) */
+
+#define ANEMOI_ALL_DEVICES (-1)
+
+#define ANEMOI_OK 0
+#define ANEMOI_ERR_FIELD (-1)  /* unknown field id */
+#define ANEMOI_ERR_WIDTH (-2)  /* width is not 2 or 4 */
+#define ANEMOI_ERR_ARG (-3)    /* null pointer, unsupported k, depth out of range (reference: assert!) */
+#define ANEMOI_ERR_DEVICE (-4) /* no such device, or a HIP call failed: see anemoi_last_error() */
+#define ANEMOI_ERR_ALLOC (-5)  /* device or host allocation failed */
+
+/* ---- introspection ---------------------------------------------------------------------- */
+int anemoi_abi_version(void);
+int anemoi_device_count(void);               /* visible HIP devices, or a negative error */
+const char *anemoi_strerror(int code);
+const char *anemoi_last_error(void);         /* thread-local detail of the last ANEMOI_ERR_DEVICE */
+int anemoi_field_id(const char *name);       /* "bls12_381" -> 0 ...; ANEMOI_ERR_FIELD if unknown */
+const char *anemoi_field_name(int field);
+int anemoi_field_limbs(int field);           /* u64 limbs per element */
+int anemoi_field_chunk_bytes(int field);     /* 31 or 47: bytes absorbed per element by hash() */
+int anemoi_num_rounds(int field, int width); /* NUM_HASH_ROUNDS, src/<f>/anemoi_x/mod.rs:31 */
+
+/* ---- host-pointer batch API -------------------------------------------------------------- */
+
+/* Anemoi::permutation (src/traits.rs:370-378) on n states of `width` elements, in place. */
+int anemoi_permutation_batch(int field, int width, uint64_t *states, size_t n, int device);
+
+/* Anemoi::sbox_layer (src/traits.rs:326-358) on n states, in place: the unit pinned by the
+ * reference's test_sbox vectors (src/<f>/anemoi_x/mod.rs:68). */
+int anemoi_sbox_layer_batch(int field, int width, uint64_t *states, size_t n, int device);
+
+/* Jive::compress (src/<f>/anemoi_2_1/hasher.rs:96-103, anemoi_4_3/hasher.rs:148-160):
+ * in = n x width elements, out = n x (width/2) elements. */
+int anemoi_jive_compress_batch(int field, int width, const uint64_t *in, uint64_t *out, size_t n, int device);
+
+/* Jive::compress_k (anemoi_2_1/hasher.rs:105-110 accepts only k = 2; anemoi_4_3/hasher.rs:162-179
+ * accepts k = 2, 4): out = n x (width/k) elements.  Other k -> ANEMOI_ERR_ARG. */
+int anemoi_jive_compress_k_batch(int field, int width, int k, const uint64_t *in, uint64_t *out, size_t n,
+                                 int device);
+
+/* Sponge::merge of the 2-1 instances (anemoi_2_1/hasher.rs:87-92) = Jive compress of [left,right]:
+ * pairs = n x 2 digests, out = n digests.  (The 4-3 merge is built on anemoi_permutation_batch by
+ * the host shim so that the reference's behaviour there is preserved, see INTEGRATION.md.) */
+int anemoi_merge_batch(int field, const uint64_t *pairs, uint64_t *out, size_t n, int device);
+
+/* Sponge::hash_field (anemoi_2_1/hasher.rs:68-85, anemoi_4_3/hasher.rs:93-129) on n messages of
+ * elems_per_msg elements each (contiguous); out = n digests (1 element each). */
+int anemoi_hash_field_batch(int field, int width, const uint64_t *elems, size_t elems_per_msg, size_t n,
+                            uint64_t *out, int device);
+
+/* Sponge::hash (anemoi_2_1/hasher.rs:18-66, anemoi_4_3/hasher.rs:19-91) on n messages of msg_len
+ * bytes each (contiguous): 31/47-byte little-endian chunks, 0x01 appended to a short last chunk. */
+int anemoi_hash_bytes_batch(int field, int width, const uint8_t *msgs, size_t msg_len, size_t n, uint64_t *out,
+                            int device);
+
+/* Root of the binary Merkle tree over 2^depth leaf digests built with the 2-1 instance's merge,
+ * level by level (depth 0 returns the leaf; depth <= 30).  With ANEMOI_ALL_DEVICES each GPU
+ * builds a contiguous subtree and the top log2(#GPUs) levels finish on the first device. */
+int anemoi_merkle_root(int field, const uint64_t *leaves, unsigned depth, uint64_t *root, int device);
+
+/* canonical little-endian integers (< p) <-> Montgomery elements.  from_montgomery's output is
+ * exactly AnemoiDigest::to_bytes (src/<f>/anemoi_x/digest.rs:42-46) when viewed as bytes. */
+int anemoi_to_montgomery(int field, const uint64_t *in, uint64_t *out, size_t count, int device);
+int anemoi_from_montgomery(int field, const uint64_t *in, uint64_t *out, size_t count, int device);
+
+/* ---- device-pointer API (buffers in the current device's HBM; asynchronous on `stream`) --- */
+int anemoi_permutation_dev(int field, int width, void *d_states, size_t n, void *stream);
+int anemoi_sbox_layer_dev(int field, int width, void *d_states, size_t n, void *stream);
+int anemoi_jive_compress_k_dev(int field, int width, int k, const void *d_in, void *d_out, size_t n, void *stream);
+int anemoi_hash_field_dev(int field, int width, const void *d_elems, size_t elems_per_msg, size_t n, void *d_out,
+                          void *stream);
+int anemoi_hash_bytes_dev(int field, int width, const void *d_msgs, size_t msg_len, size_t n, void *d_out,
+                          void *stream);
+/* d_scratch: at least 2^depth elements; d_root: 1 element; d_leaves is not modified. */
+int anemoi_merkle_root_dev(int field, const void *d_leaves, unsigned depth, void *d_scratch, void *d_root,
+                           void *stream);
+int anemoi_to_montgomery_dev(int field, const void *d_in, void *d_out, size_t count, void *stream);
+int anemoi_from_montgomery_dev(int field, const void *d_in, void *d_out, size_t count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANEMOI_MI355X_H */

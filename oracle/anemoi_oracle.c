@@ -90,8 +90,10 @@ INL void fe_sub(uint64_t *r, const uint64_t *a, const uint64_t *b, const orc_fie
 INL void fe_mul(uint64_t *r, const uint64_t *a, const uint64_t *b, const orc_field *F, int n) {
   uint64_t t[ORC_MAXL + 2];
   for (int i = 0; i < n + 2; i++) t[i] = 0;
+  _Pragma("GCC unroll 8")
   for (int i = 0; i < n; i++) {
     uint64_t c = 0;
+    _Pragma("GCC unroll 8")
     for (int j = 0; j < n; j++) {
       u128 s = (u128)a[j] * b[i] + t[j] + c;
       t[j] = (uint64_t)s;
@@ -103,6 +105,7 @@ INL void fe_mul(uint64_t *r, const uint64_t *a, const uint64_t *b, const orc_fie
     uint64_t m = t[0] * F->n0inv;
     s = (u128)m * F->p[0] + t[0];
     c = (uint64_t)(s >> 64);
+    _Pragma("GCC unroll 8")
     for (int j = 1; j < n; j++) {
       s = (u128)m * F->p[j] + t[j] + c;
       t[j - 1] = (uint64_t)s;

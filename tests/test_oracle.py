@@ -98,3 +98,22 @@ def test_batch_threads_match_single(oracle):
     b = oracle.compress_batch(fid, width, st, threads=4)
     assert (a == b).all()
     assert (a[5] == oracle.compress_k(fid, width, st[5], 2)).all()
+
+
+def test_c_oracle_matches_minted_goldens(oracle):
+    """tests/golden/extra.json is minted from the Python restatement (tools/mint_goldens.py); the C
+    oracle must reproduce it (cross-check of the two restatements on the unpinned cases)."""
+    import json, os
+    from conftest import ROOT
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "extra.json")))
+    for v in g["hash_bytes"]:
+        fid = FIELD_IDS.index(v["field"])
+        assert oracle.mont_to_ints(fid, oracle.hash_bytes(fid, v["width"], bytes.fromhex(v["msg_hex"]))) == [int(v["digest"])]
+    for v in g["compress"]:
+        fid = FIELD_IDS.index(v["field"])
+        got = oracle.compress_k(fid, v["width"], oracle.ints_to_mont(fid, ints(v["in"])), 2)
+        assert oracle.mont_to_ints(fid, got) == ints(v["out"])
+    for v in g["merkle"]:
+        fid = FIELD_IDS.index(v["field"])
+        got = oracle.merkle_root(fid, oracle.ints_to_mont(fid, ints(v["leaves"])), v["depth"])
+        assert oracle.mont_to_ints(fid, got) == [int(v["root"])]
