@@ -20,19 +20,22 @@ namespace anemoi {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: the LDS window table is lane-private
 
+#ifndef ANEMOI_WIN
+#define ANEMOI_WIN 4
+#endif
 template <int N>
 struct KernelCfg {
-  static constexpr int WIN = 4;  // sliding-window bits -> 8 odd powers per lane in LDS
+  static constexpr int WIN = ANEMOI_WIN;  // sliding-window bits -> 2^(WIN-1) odd powers per lane in LDS
 };
 
-template <int N, int WIN>
+template <class A, int WIN>
 constexpr size_t lds_table_bytes() {
-  return size_t(1 << (WIN - 1)) * N * 4 * kBlock;
+  return size_t((1 << (WIN - 1)) - 1) * A::NQ * 16 * kBlock;  // x^3, x^5, ..: x itself stays in VGPRs
 }
 
-template <int N, int WIN, int W>
+template <class A, int WIN, int W>
 constexpr size_t lds_bytes() {
-  size_t tab = lds_table_bytes<N, WIN>(), stage = size_t(W) * N * 4 * kBlock;
+  size_t tab = lds_table_bytes<A, WIN>(), stage = size_t(W) * A::NABI * 4 * kBlock;
   return tab > stage ? tab : stage;
 }
 
@@ -62,28 +65,33 @@ __device__ __forceinline__ void block_store(uint4* lds, uint4* __restrict__ g, s
   }
 }
 
-template <int N>
-__device__ __forceinline__ void lds_get(const uint4* lds, int slot, Fe<N>& v) {
+// ABI element `slot` of the staging area -> registers (internal form), and back
+template <class A>
+__device__ __forceinline__ void lds_get(const uint4* lds, int slot, typename A::Fe& v) {
+  uint32_t w[A::NABI];
 #pragma unroll
-  for (int q = 0; q < N / 4; q++) {
-    uint4 t = lds[slot * (N / 4) + q];
-    v.l[4 * q] = t.x;
-    v.l[4 * q + 1] = t.y;
-    v.l[4 * q + 2] = t.z;
-    v.l[4 * q + 3] = t.w;
+  for (int q = 0; q < A::NABI / 4; q++) {
+    uint4 t = lds[slot * (A::NABI / 4) + q];
+    w[4 * q] = t.x;
+    w[4 * q + 1] = t.y;
+    w[4 * q + 2] = t.z;
+    w[4 * q + 3] = t.w;
   }
+  A::from_abi(v, w);
 }
 
-template <int N>
-__device__ __forceinline__ void lds_put(uint4* lds, int slot, const Fe<N>& v) {
+template <class A>
+__device__ __forceinline__ void lds_put(uint4* lds, int slot, const typename A::Fe& v) {
+  uint32_t w[A::NABI];
+  A::to_abi(w, v);
 #pragma unroll
-  for (int q = 0; q < N / 4; q++)
-    lds[slot * (N / 4) + q] = make_uint4(v.l[4 * q], v.l[4 * q + 1], v.l[4 * q + 2], v.l[4 * q + 3]);
+  for (int q = 0; q < A::NABI / 4; q++)
+    lds[slot * (A::NABI / 4) + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
-template <int N>
-__device__ __forceinline__ LdsTable<N> make_table(uint4* lds) {
-  LdsTable<N> t;
+template <class A>
+__device__ __forceinline__ LdsTable<A> make_table(uint4* lds) {
+  LdsTable<A> t;
   t.base = lds + threadIdx.x;
   t.stride = kBlock;
   return t;
@@ -96,24 +104,21 @@ __device__ __forceinline__ LdsTable<N> make_table(uint4* lds) {
 template <int FIELD, int W, bool SBOX_ONLY>
 __global__ __launch_bounds__(kBlock) void k_permutation(uint4* __restrict__ states, size_t n, PermConsts pc) {
   using F = FieldC<FIELD>;
-  constexpr int N = F::N, WIN = KernelCfg<N>::WIN, PER = W * N / 4;
+  using A = ArithFor<FIELD>;
+  constexpr int WIN = KernelCfg<F::N>::WIN, PER = W * A::NABI / 4;
   extern __shared__ uint4 lds[];
   const size_t blk0 = size_t(blockIdx.x) * kBlock;
   const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
   block_load<PER>(lds, states, blk0, cnt);
-  Fe<N> st[W];
+  typename A::Fe st[W];
 #pragma unroll
-  for (int i = 0; i < W; i++) lds_get<N>(lds, threadIdx.x * W + i, st[i]);
+  for (int i = 0; i < W; i++) lds_get<A>(lds, threadIdx.x * W + i, st[i]);
   __syncthreads();
-  if (SBOX_ONLY) {
-    flystel<F, WIN>(st[0], st[W / 2], pc, make_table<N>(lds));
-    if (W == 4) flystel<F, WIN>(st[1], st[3], pc, make_table<N>(lds));
-  } else {
-    permutation<F, W, WIN>(st, pc, make_table<N>(lds));
-  }
+  if (SBOX_ONLY) sbox_layer<F, A, W, WIN>(st, pc, make_table<A>(lds));
+  else permutation<F, A, W, WIN>(st, pc, make_table<A>(lds));
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < W; i++) lds_put<N>(lds, threadIdx.x * W + i, st[i]);
+  for (int i = 0; i < W; i++) lds_put<A>(lds, threadIdx.x * W + i, st[i]);
   block_store<PER>(lds, states, blk0, cnt);
 }
 
@@ -122,48 +127,48 @@ template <int FIELD, int W, int K>
 __global__ __launch_bounds__(kBlock) void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n,
                                                  PermConsts pc) {
   using F = FieldC<FIELD>;
-  constexpr int N = F::N, WIN = KernelCfg<N>::WIN, PER = W * N / 4, C = W / K;
+  using A = ArithFor<FIELD>;
+  constexpr int WIN = KernelCfg<F::N>::WIN, PER = W * A::NABI / 4, C = W / K;
   extern __shared__ uint4 lds[];
   const size_t blk0 = size_t(blockIdx.x) * kBlock;
   const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
   block_load<PER>(lds, in, blk0, cnt);
-  Fe<N> st[W], sum[C];
+  typename A::Fe st[W], sum[C];
 #pragma unroll
-  for (int i = 0; i < W; i++) lds_get<N>(lds, threadIdx.x * W + i, st[i]);
+  for (int i = 0; i < W; i++) lds_get<A>(lds, threadIdx.x * W + i, st[i]);
   __syncthreads();
-  permutation<F, W, WIN>(st, pc, make_table<N>(lds));
+  permutation<F, A, W, WIN>(st, pc, make_table<A>(lds));
 #pragma unroll
   for (int i = 0; i < C; i++) {
     sum[i] = st[i];
 #pragma unroll
-    for (int j = 1; j < K; j++) fe_add<F>(sum[i], sum[i], st[i + C * j]);
+    for (int j = 1; j < K; j++) A::add(sum[i], sum[i], st[i + C * j]);
   }
   // Jive feed-forward: the inputs are fetched again (L2-resident, 96 B per item) instead of
-  // being held in 12-24 VGPRs across the whole permutation
+  // being held in 12-28 VGPRs across the whole permutation
   __syncthreads();
   block_load<PER>(lds, in, blk0, cnt);
 #pragma unroll
-  for (int i = 0; i < W; i++) lds_get<N>(lds, threadIdx.x * W + i, st[i]);
+  for (int i = 0; i < W; i++) lds_get<A>(lds, threadIdx.x * W + i, st[i]);
 #pragma unroll
   for (int i = 0; i < C; i++) {
 #pragma unroll
-    for (int j = 0; j < K; j++) fe_add<F>(sum[i], sum[i], st[i + C * j]);
+    for (int j = 0; j < K; j++) A::add(sum[i], sum[i], st[i + C * j]);
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < C; i++) lds_put<N>(lds, threadIdx.x * C + i, sum[i]);
-  block_store<C * N / 4>(lds, out, blk0, cnt);
+  for (int i = 0; i < C; i++) lds_put<A>(lds, threadIdx.x * C + i, sum[i]);
+  block_store<C * A::NABI / 4>(lds, out, blk0, cnt);
 }
 
-// One chunk of a byte message -> Montgomery element (from_le_bytes_mod_order + the reference's
-// padding rule: a SHORT last chunk gets a 0x01 byte appended; hasher.rs:36-57).
-template <class F>
-__device__ __forceinline__ void chunk_to_fe(Fe<F::N>& e, const uint8_t* __restrict__ p, int len) {
-  constexpr int N = F::N;
-  Fe<N> v, r2;
+// One chunk of a byte message -> internal Montgomery element (from_le_bytes_mod_order + the
+// reference's padding rule: a SHORT last chunk gets a 0x01 byte appended; hasher.rs:36-57).
+template <class F, class A>
+__device__ __forceinline__ void chunk_to_fe(typename A::Fe& e, const uint8_t* __restrict__ p, int len) {
+  uint32_t w[A::NABI];
 #pragma unroll
-  for (int i = 0; i < N; i++) {
-    uint32_t w = 0;
+  for (int i = 0; i < A::NABI; i++) {
+    uint32_t v = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
       const int pos = 4 * i + b;
@@ -172,86 +177,87 @@ __device__ __forceinline__ void chunk_to_fe(Fe<F::N>& e, const uint8_t* __restri
         if (pos < len) byte = p[pos];
         else if (pos == len) byte = 1;  // only reachable when len < kChunk
       }
-      w |= byte << (8 * b);
+      v |= byte << (8 * b);
     }
-    v.l[i] = w;
-    r2.l[i] = F::R2[i];
+    w[i] = v;
   }
   // value < 2^(8*kChunk+1) < p: already reduced; enter Montgomery form
-  mont_mul<F, true>(e, v, r2);
+  A::from_int(e, w);
 }
 
-// Sponge over `num` elements per message (BYTES: taken from msg_len-byte messages; else Montgomery
+// Sponge over `num` elements per message (BYTES: taken from msg_len-byte messages; else ABI
 // elements).  Unified rule (== both hasher.rs variants): absorb into state[i]; permute when
 // i == RATE; if num % RATE != 0 absorb a final 1 and permute; digest = state[0].
 template <int FIELD, int W, bool BYTES>
 __global__ __launch_bounds__(kBlock) void k_sponge(const void* __restrict__ src, size_t per_msg, size_t n,
                                                    uint4* __restrict__ out, PermConsts pc) {
   using F = FieldC<FIELD>;
-  constexpr int N = F::N, WIN = KernelCfg<N>::WIN, RATE = W - 1;
+  using A = ArithFor<FIELD>;
+  constexpr int WIN = KernelCfg<F::N>::WIN, RATE = W - 1;
   extern __shared__ uint4 lds[];
   const size_t blk0 = size_t(blockIdx.x) * kBlock;
   const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
   const size_t item = blk0 + (threadIdx.x < cnt ? threadIdx.x : 0);  // idle lanes redo item blk0
   const size_t num = BYTES ? (per_msg + F::kChunk - 1) / F::kChunk : per_msg;
   const size_t total = num + (num % RATE == 0 ? 0 : 1);
-  const uint8_t* msg = (const uint8_t*)src + (BYTES ? item * per_msg : item * per_msg * N * 4);
-  Fe<N> st[W];
+  const uint8_t* msg = (const uint8_t*)src + (BYTES ? item * per_msg : item * per_msg * A::NABI * 4);
+  typename A::Fe st[W];
 #pragma unroll
-  for (int i = 0; i < W; i++)
-#pragma unroll
-    for (int l = 0; l < N; l++) st[i].l[l] = 0;
+  for (int i = 0; i < W; i++) A::set_zero(st[i]);
   int pos = 0;
-  const LdsTable<N> tab = make_table<N>(lds);
+  const LdsTable<A> tab = make_table<A>(lds);
 #pragma nounroll
   for (size_t e = 0; e < total; e++) {
-    Fe<N> el;
+    typename A::Fe el;
     if (e < num) {
       if (BYTES) {
         const size_t off = e * F::kChunk;
         const size_t left = per_msg - off;
-        chunk_to_fe<F>(el, msg + off, left < size_t(F::kChunk) ? int(left) : F::kChunk);
+        chunk_to_fe<F, A>(el, msg + off, left < size_t(F::kChunk) ? int(left) : F::kChunk);
       } else {
-        const uint32_t* w = (const uint32_t*)msg + e * N;
+        const uint32_t* src32 = (const uint32_t*)msg + e * A::NABI;
+        uint32_t w[A::NABI];
 #pragma unroll
-        for (int l = 0; l < N; l++) el.l[l] = w[l];
+        for (int l = 0; l < A::NABI; l++) w[l] = src32[l];
+        A::from_abi(el, w);
       }
     } else {
-#pragma unroll
-      for (int l = 0; l < N; l++) el.l[l] = F::One[l];
+      A::set_one(el);
     }
     // pos is wave-uniform (every message has the same length)
-    if (RATE == 1 || pos == 0) fe_add<F>(st[0], st[0], el);
-    else if (pos == 1) fe_add<F>(st[1], st[1], el);
-    else fe_add<F>(st[RATE - 1], st[RATE - 1], el);
+    if (RATE == 1 || pos == 0) A::add(st[0], st[0], el);
+    else if (pos == 1) A::add(st[1], st[1], el);
+    else A::add(st[RATE - 1], st[RATE - 1], el);
     pos++;
     if (pos == RATE || e == total - 1) {
-      permutation<F, W, WIN>(st, pc, tab);
+      permutation<F, A, W, WIN>(st, pc, tab);
       pos = 0;
     }
   }
   __syncthreads();
-  lds_put<N>(lds, threadIdx.x, st[0]);
-  block_store<N / 4>(lds, out, blk0, cnt);
+  lds_put<A>(lds, threadIdx.x, st[0]);
+  block_store<A::NABI / 4>(lds, out, blk0, cnt);
 }
 
-// to = true: canonical -> Montgomery (x * R^2 / R); to = false: Montgomery -> canonical (x * 1 / R)
+// to = true: canonical -> Montgomery (x * R^2 / R); to = false: Montgomery -> canonical (x * 1 / R).
+// Always on 32-bit limbs: this is the ABI's own R = 2^(32 N).
 template <int FIELD>
 __global__ __launch_bounds__(kBlock) void k_mont_convert(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                          size_t count, int to) {
   using F = FieldC<FIELD>;
+  using A = Arith32<F>;
   constexpr int N = F::N;
   extern __shared__ uint4 lds[];
   const size_t blk0 = size_t(blockIdx.x) * kBlock;
   const int cnt = count - blk0 < size_t(kBlock) ? int(count - blk0) : kBlock;
   block_load<N / 4>(lds, in, blk0, cnt);
   Fe<N> v, k;
-  lds_get<N>(lds, threadIdx.x, v);
+  lds_get<A>(lds, threadIdx.x, v);
 #pragma unroll
   for (int i = 0; i < N; i++) k.l[i] = to ? F::R2[i] : (i == 0 ? 1u : 0u);
   mont_mul<F, true>(v, v, k);
   __syncthreads();
-  lds_put<N>(lds, threadIdx.x, v);
+  lds_put<A>(lds, threadIdx.x, v);
   block_store<N / 4>(lds, out, blk0, cnt);
 }
 
@@ -281,48 +287,59 @@ inline unsigned grid_for(size_t n) { return unsigned((n + kBlock - 1) / kBlock);
 template <int FIELD>
 struct Launch {
   using F = FieldC<FIELD>;
+  using A = ArithFor<FIELD>;
   static constexpr int N = F::N, WIN = KernelCfg<N>::WIN;
 
   static void host_consts(int width, HostConsts* hc) {
-    const uint32_t* c = width == 2 ? F::ArkC21 : F::ArkC43;
-    const uint32_t* d = width == 2 ? F::ArkD21 : F::ArkD43;
-    const int cnt = (width == 2 ? F::kRounds21 : 2 * F::kRounds43) * N;
+    const uint32_t* c = A::host_ark(width, false);
+    const uint32_t* d = A::host_ark(width, true);
+    const int cnt = (width == 2 ? F::kRounds21 : 2 * F::kRounds43) * A::NL;
     hc->ark_c.assign(c, c + cnt);
     hc->ark_d.assign(d, d + cnt);
-    static_assert(WIN == 4, "schedule selection below assumes the 4-bit window");
-    hc->sched.assign(F::kW4Sched, F::kW4Sched + 2 * F::kW4Steps);
-    hc->steps = F::kW4Steps;
-    hc->first = F::kW4First;
+    static_assert(WIN >= 2 && WIN <= 5, "schedules are generated for 2..5-bit windows");
+    if (WIN == 2) {
+      hc->sched.assign(F::kW2Sched, F::kW2Sched + 2 * F::kW2Steps);
+      hc->steps = F::kW2Steps, hc->first = F::kW2First;
+    } else if (WIN == 3) {
+      hc->sched.assign(F::kW3Sched, F::kW3Sched + 2 * F::kW3Steps);
+      hc->steps = F::kW3Steps, hc->first = F::kW3First;
+    } else if (WIN == 4) {
+      hc->sched.assign(F::kW4Sched, F::kW4Sched + 2 * F::kW4Steps);
+      hc->steps = F::kW4Steps, hc->first = F::kW4First;
+    } else {
+      hc->sched.assign(F::kW5Sched, F::kW5Sched + 2 * F::kW5Steps);
+      hc->steps = F::kW5Steps, hc->first = F::kW5First;
+    }
   }
 
   static hipError_t permutation(int width, int sbox_only, void* d, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
     if (width == 2 && !sbox_only)
-      k_permutation<FIELD, 2, false><<<grid_for(n), kBlock, lds_bytes<N, WIN, 2>(), s>>>((uint4*)d, n, pc);
+      k_permutation<FIELD, 2, false><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((uint4*)d, n, pc);
     else if (width == 2)
-      k_permutation<FIELD, 2, true><<<grid_for(n), kBlock, lds_bytes<N, WIN, 2>(), s>>>((uint4*)d, n, pc);
+      k_permutation<FIELD, 2, true><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((uint4*)d, n, pc);
     else if (!sbox_only)
-      k_permutation<FIELD, 4, false><<<grid_for(n), kBlock, lds_bytes<N, WIN, 4>(), s>>>((uint4*)d, n, pc);
+      k_permutation<FIELD, 4, false><<<grid_for(n), kBlock, lds_bytes<A, WIN, 4>(), s>>>((uint4*)d, n, pc);
     else
-      k_permutation<FIELD, 4, true><<<grid_for(n), kBlock, lds_bytes<N, WIN, 4>(), s>>>((uint4*)d, n, pc);
+      k_permutation<FIELD, 4, true><<<grid_for(n), kBlock, lds_bytes<A, WIN, 4>(), s>>>((uint4*)d, n, pc);
     return hipGetLastError();
   }
 
   static hipError_t jive(int width, int k, const void* in, void* out, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
     if (width == 2)
-      k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, lds_bytes<N, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+      k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     else if (k == 2)
-      k_jive<FIELD, 4, 2><<<grid_for(n), kBlock, lds_bytes<N, WIN, 4>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+      k_jive<FIELD, 4, 2><<<grid_for(n), kBlock, lds_bytes<A, WIN, 4>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     else
-      k_jive<FIELD, 4, 4><<<grid_for(n), kBlock, lds_bytes<N, WIN, 4>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+      k_jive<FIELD, 4, 4><<<grid_for(n), kBlock, lds_bytes<A, WIN, 4>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     return hipGetLastError();
   }
 
   static hipError_t sponge(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
                            hipStream_t s) {
     if (!n) return hipSuccess;
-    const size_t l = lds_bytes<N, WIN, 1>();
+    const size_t l = lds_bytes<A, WIN, 1>();
     if (width == 2 && bytes)
       k_sponge<FIELD, 2, true><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc);
     else if (width == 2)

@@ -7,42 +7,45 @@
 //   round       :361-367   ark ; mds ; sbox
 //   permutation :370-378   NUM_ROUNDS rounds, then one more mds_layer
 // and replaces the per-field hard-coded addition chain `exp_by_inv_alpha` (src/<field>/sbox.rs) by
-// a sliding-window exponentiation whose table of odd powers lives in LDS (one private column per
-// lane, 16-byte interleaved so every ds_read_b128/ds_write_b128 is conflict-free).  x^INV_ALPHA is a
-// canonical field value, so any exponentiation schedule is bit-identical to the reference's chain.
+// a sliding-window exponentiation: x^INV_ALPHA is a canonical field value, so any exponentiation
+// schedule is bit-identical to the reference's chain.  x itself stays in registers (the S-box
+// needs it afterwards anyway); the higher odd powers x^3, x^5, .. live in LDS, one private column
+// per lane, 16-byte interleaved so every ds_read_b128 / ds_write_b128 is conflict-free.
+//
+// The arithmetic is a policy `A` (Arith32 in mont32.h, Arith29 in mont29.h).  With a "loose"
+// policy (Arith29) additions do not reduce; values are bounded by the bookkeeping in the comments
+// below (units of p), and `settle` brings a value back below 2p.
 #pragma once
+#include <type_traits>
+
 #include "field_consts_gen.h"
+#include "mont29.h"
 #include "mont32.h"
 
 namespace anemoi {
 
-// Per-lane window table in LDS.  Entry e, 16-byte quad q of this lane sits at
-// base[(e * Q + q) * stride]; `base` already points at the lane's own slot.
-template <int N>
-struct LdsTable {
-  static constexpr int Q = N / 4;
-  uint4* base;
-  int stride;  // in uint4 = number of lanes sharing the table block
+// 6-limb fields (BLS12-381 / BLS12-377) run on 29-bit unsaturated limbs; the 4-limb fields stay on
+// 32-bit limbs this round (their R'/p headroom is only 2^6..2^9).
+template <int FIELD>
+using ArithFor = std::conditional_t<FieldC<FIELD>::L64 == 6, Arith29<FieldC<FIELD>>, Arith32<FieldC<FIELD>>>;
 
-  __device__ __forceinline__ void store(int e, const Fe<N>& v) const {
-#pragma unroll
-    for (int q = 0; q < Q; q++)
-      base[(e * Q + q) * stride] = make_uint4(v.l[4 * q], v.l[4 * q + 1], v.l[4 * q + 2], v.l[4 * q + 3]);
+// Per-lane window table in LDS: entries 1.. = x^3, x^5, ...; entry e, slot q of this lane at
+// base[((e-1) * NQ + q) * stride].
+template <class A>
+struct LdsTable {
+  uint4* base;  // already offset to the lane's own column
+  int stride;   // uint4 between consecutive slots = lanes per block
+  __device__ __forceinline__ void store(int e, const typename A::Fe& v) const {
+    A::lds_store(base + (e - 1) * A::NQ * stride, stride, v);
   }
-  __device__ __forceinline__ void load(int e, Fe<N>& v) const {
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-      uint4 t = base[(e * Q + q) * stride];
-      v.l[4 * q] = t.x;
-      v.l[4 * q + 1] = t.y;
-      v.l[4 * q + 2] = t.z;
-      v.l[4 * q + 3] = t.w;
-    }
+  __device__ __forceinline__ void load(int e, typename A::Fe& v) const {
+    A::lds_load(base + (e - 1) * A::NQ * stride, stride, v);
   }
 };
 
 // Per-(field, width) constants in device memory, uploaded once by the host context:
-//   ark   : C then D, each cols*rounds elements of N Montgomery limbs (uniform -> scalar loads)
+//   ark   : C then D, each cols*rounds elements of A::NL limbs in A's Montgomery form (wave-uniform
+//           addresses -> scalar loads)
 //   sched : sliding-window schedule, pairs (squarings, table index | 255), `steps` of them
 struct PermConsts {
   const uint32_t* ark_c;
@@ -52,104 +55,121 @@ struct PermConsts {
   int first;
 };
 
-// r = x^INV_ALPHA (canonical in, canonical out).  WIN-bit sliding window over odd powers.
-template <class F, int WIN>
-__device__ __forceinline__ void exp_inv_alpha(Fe<F::N>& r, const Fe<F::N>& x, const PermConsts& pc,
-                                              const LdsTable<F::N>& tab) {
+// r = x^INV_ALPHA.  WIN-bit sliding window over odd powers; table entry 0 is x itself (registers).
+// In: x < 2^12 p (loose) or canonical.  Out: < 2p (loose) or canonical.
+template <class F, class A, int WIN>
+__device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename A::Fe& x, const PermConsts& pc,
+                                              const LdsTable<A>& tab) {
   constexpr int E = 1 << (WIN - 1);
-  Fe<F::N> x2, t;
-  mont_sqr<F, false>(x2, x);
+  typename A::Fe x2, t, acc;
+  A::esqr(x2, x);
   t = x;
-  tab.store(0, t);
 #pragma nounroll
   for (int i = 1; i < E; i++) {
-    mont_mul<F, false>(t, t, x2);
+    A::emul(t, t, x2);
     tab.store(i, t);
   }
-  Fe<F::N> acc;
-  tab.load(pc.first, acc);
+  if (pc.first == 0) acc = x;
+  else tab.load(pc.first, acc);
 #pragma nounroll
   for (int s = 0; s < pc.steps; s++) {
     const int nsq = pc.sched[2 * s], idx = pc.sched[2 * s + 1];
 #pragma nounroll
-    for (int q = 0; q < nsq; q++) mont_sqr<F, false>(acc, acc);
+    for (int q = 0; q < nsq; q++) A::esqr(acc, acc);
     if (idx != 255) {
-      tab.load(idx, t);
-      mont_mul<F, false>(acc, acc, t);
+      if (idx == 0) t = x;
+      else tab.load(idx, t);
+      A::emul(acc, acc, t);
     }
   }
-  if (F::kLazy) fe_reduce_once<F>(acc);
+  A::efinish(acc);
   r = acc;
 }
 
-// Flystel S-box on one column (src/traits.rs:326-358)
-template <class F, int WIN>
-__device__ __forceinline__ void flystel(Fe<F::N>& x, Fe<F::N>& y, const PermConsts& pc, const LdsTable<F::N>& tab) {
-  Fe<F::N> t, u;
-  mont_sqr<F, true>(t, y);
-  fe_mul_g<F>(u, t);
-  fe_sub<F>(x, x, u);
-  exp_inv_alpha<F, WIN>(t, x, pc, tab);
-  fe_sub<F>(y, y, t);
-  mont_sqr<F, true>(t, y);
-  fe_mul_g<F>(u, t);
-  fe_add<F>(x, x, u);
-  fe_add_const<F>(x, x, F::Delta);
+// Flystel S-box on one column (src/traits.rs:326-358).
+// Loose bounds (units of p), entering with x, y < 2 after settle():
+//   u = g*y^2 < 2g <= 30 ; x' = x + 64p - u < 66 ; t = x'^(1/alpha) < 2 ; y' = y + 64p - t < 66 ;
+//   x'' = x' + g*y'^2 + delta < 66 + 30 + 1 = 97.   (all far below 2^12, the multiplier's limit)
+template <class F, class A, int WIN>
+__device__ __forceinline__ void flystel(typename A::Fe& x, typename A::Fe& y, const PermConsts& pc,
+                                        const LdsTable<A>& tab) {
+  typename A::Fe t, u;
+  A::sqr(t, y);
+  A::mul_g(u, t);
+  A::sub(x, x, u);
+  exp_inv_alpha<F, A, WIN>(t, x, pc, tab);
+  A::sub(y, y, t);
+  A::sqr(t, y);
+  A::mul_g(u, t);
+  A::add(x, x, u);
+  A::add_delta(x, x);
 }
 
-// Linear layer (src/traits.rs:136-157)
-template <class F, int W>
-__device__ __forceinline__ void mds_layer(Fe<F::N> (&st)[W]) {
+// Linear layer (src/traits.rs:136-157).
+// Loose bounds: W=2 entering < 98: y < 196, x < 294.  W=4, g <= 15, entering < 98:
+// x0 < 98+15*98 = 1568, x1 < 98+15*1568 < 2^15, same for y; after the PHT step < 2^17 -- additions
+// only, then settle() (valid for inputs < 2^25 p).
+template <class F, class A, int W>
+__device__ __forceinline__ void mds_layer(typename A::Fe (&st)[W]) {
   if (W == 2) {
-    fe_add<F>(st[1], st[1], st[0]);
-    fe_add<F>(st[0], st[0], st[1]);
+    A::add(st[1], st[1], st[0]);
+    A::add(st[0], st[0], st[1]);
   } else {
-    Fe<F::N> t;
-    fe_mul_g<F>(t, st[1]);
-    fe_add<F>(st[0], st[0], t);
-    fe_mul_g<F>(t, st[0]);
-    fe_add<F>(st[1], st[1], t);
-    fe_mul_g<F>(t, st[2]);
-    fe_add<F>(st[3], st[3], t);
-    fe_mul_g<F>(t, st[3]);
-    fe_add<F>(st[2], st[2], t);
+    typename A::Fe t;
+    A::mul_g(t, st[1]);
+    A::add(st[0], st[0], t);
+    A::mul_g(t, st[0]);
+    A::add(st[1], st[1], t);
+    A::mul_g(t, st[2]);
+    A::add(st[3], st[3], t);
+    A::mul_g(t, st[3]);
+    A::add(st[2], st[2], t);
     t = st[2];
     st[2] = st[3];
     st[3] = t;
-    fe_add<F>(st[2], st[2], st[0]);
-    fe_add<F>(st[3], st[3], st[1]);
-    fe_add<F>(st[0], st[0], st[2]);
-    fe_add<F>(st[1], st[1], st[3]);
+    A::add(st[2], st[2], st[0]);
+    A::add(st[3], st[3], st[1]);
+    A::add(st[0], st[0], st[2]);
+    A::add(st[1], st[1], st[3]);
+  }
+  if (A::kLoose) {
+#pragma unroll
+    for (int i = 0; i < W; i++) A::settle(st[i]);
   }
 }
 
-template <class F>
-__device__ __forceinline__ void fe_add_global(Fe<F::N>& r, const uint32_t* __restrict__ k) {
-  uint32_t c[F::N];
+template <class A>
+__device__ __forceinline__ void add_global(typename A::Fe& r, const uint32_t* __restrict__ k) {
+  uint32_t c[A::NL];
 #pragma unroll
-  for (int i = 0; i < F::N; i++) c[i] = k[i];
-  fe_add_const<F>(r, r, c);
+  for (int i = 0; i < A::NL; i++) c[i] = k[i];
+  A::add_k(r, r, c);
+}
+
+template <class F, class A, int W, int WIN>
+__device__ __forceinline__ void sbox_layer(typename A::Fe (&st)[W], const PermConsts& pc, const LdsTable<A>& tab) {
+  // columns spelled out: the S-box body is too large to unroll by pragma, and a rolled loop would
+  // index the register-resident state dynamically (scratch)
+  flystel<F, A, WIN>(st[0], st[W / 2], pc, tab);
+  if (W == 4) flystel<F, A, WIN>(st[1], st[3], pc, tab);
 }
 
 // Full permutation (src/traits.rs:370-378)
-template <class F, int W, int WIN>
-__device__ __forceinline__ void permutation(Fe<F::N> (&st)[W], const PermConsts& pc, const LdsTable<F::N>& tab) {
+template <class F, class A, int W, int WIN>
+__device__ __forceinline__ void permutation(typename A::Fe (&st)[W], const PermConsts& pc, const LdsTable<A>& tab) {
   constexpr int C = W / 2;
   constexpr int R = W == 2 ? F::kRounds21 : F::kRounds43;
 #pragma nounroll
   for (int r = 0; r < R; r++) {
 #pragma unroll
     for (int i = 0; i < C; i++) {
-      fe_add_global<F>(st[i], pc.ark_c + (r * C + i) * F::N);
-      fe_add_global<F>(st[C + i], pc.ark_d + (r * C + i) * F::N);
+      add_global<A>(st[i], pc.ark_c + (r * C + i) * A::NL);
+      add_global<A>(st[C + i], pc.ark_d + (r * C + i) * A::NL);
     }
-    mds_layer<F, W>(st);
-    // columns spelled out: the S-box body is too large for `#pragma unroll`, and a rolled loop
-    // would index the register-resident state dynamically (scratch)
-    flystel<F, WIN>(st[0], st[C], pc, tab);
-    if (C == 2) flystel<F, WIN>(st[C - 1], st[W - 1], pc, tab);
+    mds_layer<F, A, W>(st);
+    sbox_layer<F, A, W, WIN>(st, pc, tab);
   }
-  mds_layer<F, W>(st);
+  mds_layer<F, A, W>(st);
 }
 
 }  // namespace anemoi

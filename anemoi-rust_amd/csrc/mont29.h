@@ -1,0 +1,251 @@
+// mont29.h -- lane-private Montgomery arithmetic on unsaturated 29-bit limbs for gfx950 (CDNA4).
+//
+// Why not 32-bit limbs: measured on MI355X (tools/ubench/valu_rates.hip, profiles/), a
+// v_mad_u64_u32 costs the same issue time as a v_addc_co_u32 / v_lshl_add_u64 (~3.4 cycles per
+// wave-instruction at 4 waves/SIMD), and a VALU-written carry (VCC/SGPR) needs 2 wait states before
+// a VALU can consume it.  With saturated 32-bit limbs every multiply-accumulate therefore costs a
+// multiply PLUS a carry instruction.  With 29-bit limbs a whole column of the product
+// (<= 28 products < 2^58) fits a 64-bit accumulator, so a multiply-accumulate is exactly ONE
+// v_mad_u64_u32 and carries are resolved once per column (one shift, one mask):
+//     BLS12-381 squaring: 315 multiplies + ~100 cheap ops  vs  234 multiplies + 234 carries + pads.
+// The spare bits also remove every conditional subtraction: R' = 2^(29*NL) exceeds p by >= 2^25 for
+// the 381/377-bit fields, so a Montgomery product of inputs < 2^12 p is < 2p and additions /
+// subtractions need no reduction at all; values are made canonical once, on the way out.
+//
+// Element form inside the kernels: NL limbs l[i] < 2^29, value = sum l[i] 2^(29 i), Montgomery form
+// with R' = 2^(29 NL).  The C-ABI form (arkworks: 32-bit-limb R = 2^(64 L)) is converted on load
+// and store by one Montgomery product each (from_abi / to_abi), exact and bit-identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace anemoi {
+
+template <class F>
+struct Arith29 {
+  static constexpr int NL = F::NL29;   // limbs held in VGPRs
+  static constexpr int NABI = F::N;    // 32-bit words of an ABI element
+  static constexpr int NQ = (NL + 3) / 4;  // uint4 slots of one LDS table entry
+  static constexpr uint32_t MASK = (1u << 29) - 1;
+  static constexpr bool kLoose = true;  // values between reductions may exceed p (see settle())
+
+  struct Fe {
+    uint32_t l[NL];
+  };
+
+  // carry ripple: limbs back below 2^29 (the top limb keeps the excess; values stay < 2^(29 NL))
+  __device__ static __forceinline__ void norm(Fe& r) {
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+      r.l[i + 1] += r.l[i] >> 29;
+      r.l[i] &= MASK;
+    }
+  }
+
+  // Montgomery product a*b/R' mod p, result < 2p when (a/p)*(b/p) <= R'/p.  All limbs < 2^29.
+  __device__ static __forceinline__ void mul(Fe& r, const Fe& a, const Fe& b) {
+    uint32_t m[NL], out[NL];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+      for (int j = 0; j <= k; j++) acc += (uint64_t)a.l[j] * b.l[k - j];
+#pragma unroll
+      for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * F::P29[k - j];
+      m[k] = ((uint32_t)acc * F::kN0Inv29) & MASK;
+      acc += (uint64_t)m[k] * F::P29[0];
+      acc >>= 29;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+      for (int j = k - NL + 1; j < NL; j++) {
+        acc += (uint64_t)a.l[j] * b.l[k - j];
+        acc += (uint64_t)m[j] * F::P29[k - j];
+      }
+      out[k - NL] = (uint32_t)acc & MASK;
+      acc >>= 29;
+    }
+    out[NL - 1] = (uint32_t)acc;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = out[i];
+  }
+
+  // Montgomery square.  Off-diagonal products use a pre-doubled copy of a (limb-wise doubling is
+  // exact with unsaturated limbs: 2*l[i] < 2^30), so each costs one multiply-accumulate.
+  __device__ static __forceinline__ void sqr(Fe& r, const Fe& a) {
+    uint32_t m[NL], out[NL], a2[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; k++) {
+      const int j0 = k < NL ? 0 : k - NL + 1;
+#pragma unroll
+      for (int j = j0; j < k - j; j++) acc += (uint64_t)a2[j] * a.l[k - j];
+      if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+      if (k < NL) {
+#pragma unroll
+        for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * F::P29[k - j];
+        m[k] = ((uint32_t)acc * F::kN0Inv29) & MASK;
+        acc += (uint64_t)m[k] * F::P29[0];
+      } else {
+#pragma unroll
+        for (int j = k - NL + 1; j < NL; j++) acc += (uint64_t)m[j] * F::P29[k - j];
+        out[k - NL] = (uint32_t)acc & MASK;
+      }
+      acc >>= 29;
+    }
+    out[NL - 1] = (uint32_t)acc;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = out[i];
+  }
+
+  // r = a + b (no reduction; the caller keeps values < 2^12 p, see anemoi_perm.h)
+  __device__ static __forceinline__ void add(Fe& r, const Fe& a, const Fe& b) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
+    norm(r);
+  }
+
+  // r = a + k, k given as NL limbs (compile-time or wave-uniform)
+  __device__ static __forceinline__ void add_k(Fe& r, const Fe& a, const uint32_t* __restrict__ k) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + k[i];
+    norm(r);
+  }
+
+  // r = a - b + kSubK29*p >= 0  (b < ~60 p): KP29 is kSubK29*p with limbs padded to >= 2^29, so no
+  // limb goes negative
+  __device__ static __forceinline__ void sub(Fe& r, const Fe& a, const Fe& b) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + F::KP29[i] - b.l[i];
+    norm(r);
+  }
+
+  // r = g * x for the small generator g (mul_by_generator, src/traits.rs:78-91)
+  __device__ static __forceinline__ void mul_g(Fe& r, const Fe& x) {
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      acc += (uint64_t)x.l[i] * (uint32_t)F::kG;
+      r.l[i] = (uint32_t)acc & MASK;
+      acc >>= 29;
+    }
+  }
+
+  // value-preserving reduction to < 2p: x * R' / R'
+  __device__ static __forceinline__ void settle(Fe& x) {
+    Fe one;
+#pragma unroll
+    for (int i = 0; i < NL; i++) one.l[i] = F::One29[i];
+    mul(x, x, one);
+  }
+
+  __device__ static __forceinline__ void set_one(Fe& x) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) x.l[i] = F::One29[i];
+  }
+  __device__ static __forceinline__ void set_zero(Fe& x) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) x.l[i] = 0;
+  }
+  __device__ static __forceinline__ void add_delta(Fe& r, const Fe& a) { add_k(r, a, F::Delta29); }
+
+  // x < 2p (normalised) -> x mod p
+  __device__ static __forceinline__ void canonical(Fe& x) {
+    uint32_t d[NL];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      uint32_t t = x.l[i] - F::P29[i] - borrow;
+      borrow = t >> 31;
+      d[i] = t & MASK;
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) x.l[i] = borrow ? x.l[i] : d[i];
+  }
+
+  // 32-bit words (plain integer) -> 29-bit limbs (same integer)
+  __device__ static __forceinline__ void repack_in(Fe& r, const uint32_t (&w)[NABI]) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int bit = 29 * i, lo = bit >> 5, sh = bit & 31;
+      uint64_t v = 0;
+      if (lo < NABI) v = w[lo];
+      if (lo + 1 < NABI) v |= (uint64_t)w[lo + 1] << 32;
+      r.l[i] = (uint32_t)(v >> sh) & MASK;
+    }
+  }
+  // 29-bit limbs (value < 2^(32 NABI)) -> 32-bit words
+  __device__ static __forceinline__ void repack_out(uint32_t (&w)[NABI], const Fe& a) {
+#pragma unroll
+    for (int j = 0; j < NABI; j++) {
+      const int bit = 32 * j, i0 = bit / 29, off = bit - 29 * i0;
+      uint64_t v = (uint64_t)a.l[i0] >> off;
+      if (i0 + 1 < NL) v |= (uint64_t)a.l[i0 + 1] << (29 - off);
+      if (i0 + 2 < NL && 58 - off < 32) v |= (uint64_t)a.l[i0 + 2] << (58 - off);
+      w[j] = (uint32_t)v;
+    }
+  }
+
+  // ABI element (x * 2^(32 NABI) mod p, 32-bit words) -> internal (x * R' mod p), < 2p
+  __device__ static __forceinline__ void from_abi(Fe& r, const uint32_t (&w)[NABI]) {
+    Fe k;
+    repack_in(r, w);
+#pragma unroll
+    for (int i = 0; i < NL; i++) k.l[i] = F::In29[i];
+    mul(r, r, k);
+  }
+  // internal (any value < 2^12 p) -> canonical ABI element
+  __device__ static __forceinline__ void to_abi(uint32_t (&w)[NABI], const Fe& a) {
+    Fe k, t;
+#pragma unroll
+    for (int i = 0; i < NL; i++) k.l[i] = F::Out29[i];
+    mul(t, a, k);
+    canonical(t);
+    repack_out(w, t);
+  }
+  // plain integer < p (32-bit words) -> internal Montgomery form
+  __device__ static __forceinline__ void from_int(Fe& r, const uint32_t (&w)[NABI]) {
+    Fe k;
+    repack_in(r, w);
+#pragma unroll
+    for (int i = 0; i < NL; i++) k.l[i] = F::RR29[i];
+    mul(r, r, k);
+  }
+
+  // exponentiation-chain forms (same as mul/sqr here: results are always < 2p)
+  __device__ static __forceinline__ void emul(Fe& r, const Fe& a, const Fe& b) { mul(r, a, b); }
+  __device__ static __forceinline__ void esqr(Fe& r, const Fe& a) { sqr(r, a); }
+  __device__ static __forceinline__ void efinish(Fe&) {}
+
+  // LDS table entry <-> registers (NQ uint4 slots, `stride` uint4 apart)
+  __device__ static __forceinline__ void lds_store(uint4* base, int stride, const Fe& v) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      uint4 t;
+      t.x = v.l[4 * q];
+      t.y = 4 * q + 1 < NL ? v.l[4 * q + 1] : 0u;
+      t.z = 4 * q + 2 < NL ? v.l[4 * q + 2] : 0u;
+      t.w = 4 * q + 3 < NL ? v.l[4 * q + 3] : 0u;
+      base[q * stride] = t;
+    }
+  }
+  __device__ static __forceinline__ void lds_load(const uint4* base, int stride, Fe& v) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      uint4 t = base[q * stride];
+      v.l[4 * q] = t.x;
+      if (4 * q + 1 < NL) v.l[4 * q + 1] = t.y;
+      if (4 * q + 2 < NL) v.l[4 * q + 2] = t.z;
+      if (4 * q + 3 < NL) v.l[4 * q + 3] = t.w;
+    }
+  }
+
+  static const uint32_t* host_ark(int width, bool d) {
+    return width == 2 ? (d ? F::ArkD29_21 : F::ArkC29_21) : (d ? F::ArkD29_43 : F::ArkC29_43);
+  }
+};
+
+}  // namespace anemoi

@@ -341,4 +341,74 @@ __device__ __forceinline__ void fe_mul_g(Fe<F::N>& r, const Fe<F::N>& x) {
   }
 }
 
+// Policy adapter used by anemoi_perm.h / anemoi_kernels.h (same interface as Arith29 in mont29.h).
+// Values held between operations are canonical (< p); only the exponentiation chain is lazy.
+template <class F>
+struct Arith32 {
+  static constexpr int NL = F::N;
+  static constexpr int NABI = F::N;
+  static constexpr int NQ = F::N / 4;
+  static constexpr bool kLoose = false;
+  using Fe = anemoi::Fe<F::N>;
+
+  __device__ static __forceinline__ void mul(Fe& r, const Fe& a, const Fe& b) { mont_mul<F, true>(r, a, b); }
+  __device__ static __forceinline__ void sqr(Fe& r, const Fe& a) { mont_sqr<F, true>(r, a); }
+  __device__ static __forceinline__ void emul(Fe& r, const Fe& a, const Fe& b) { mont_mul<F, false>(r, a, b); }
+  __device__ static __forceinline__ void esqr(Fe& r, const Fe& a) { mont_sqr<F, false>(r, a); }
+  __device__ static __forceinline__ void efinish(Fe& a) {
+    if (F::kLazy) fe_reduce_once<F>(a);
+  }
+  __device__ static __forceinline__ void add(Fe& r, const Fe& a, const Fe& b) { fe_add<F>(r, a, b); }
+  __device__ static __forceinline__ void add_k(Fe& r, const Fe& a, const uint32_t* __restrict__ k) {
+    fe_add_const<F>(r, a, k);
+  }
+  __device__ static __forceinline__ void sub(Fe& r, const Fe& a, const Fe& b) { fe_sub<F>(r, a, b); }
+  __device__ static __forceinline__ void mul_g(Fe& r, const Fe& x) { fe_mul_g<F>(r, x); }
+  __device__ static __forceinline__ void settle(Fe&) {}
+  __device__ static __forceinline__ void add_delta(Fe& r, const Fe& a) { fe_add_const<F>(r, a, F::Delta); }
+  __device__ static __forceinline__ void set_one(Fe& x) {
+#pragma unroll
+    for (int i = 0; i < F::N; i++) x.l[i] = F::One[i];
+  }
+  __device__ static __forceinline__ void set_zero(Fe& x) {
+#pragma unroll
+    for (int i = 0; i < F::N; i++) x.l[i] = 0;
+  }
+  __device__ static __forceinline__ void from_abi(Fe& r, const uint32_t (&w)[NABI]) {
+#pragma unroll
+    for (int i = 0; i < F::N; i++) r.l[i] = w[i];
+  }
+  __device__ static __forceinline__ void to_abi(uint32_t (&w)[NABI], const Fe& a) {
+#pragma unroll
+    for (int i = 0; i < F::N; i++) w[i] = a.l[i];
+  }
+  __device__ static __forceinline__ void from_int(Fe& r, const uint32_t (&w)[NABI]) {
+    Fe v, r2;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+      v.l[i] = w[i];
+      r2.l[i] = F::R2[i];
+    }
+    mont_mul<F, true>(r, v, r2);
+  }
+  __device__ static __forceinline__ void lds_store(uint4* base, int stride, const Fe& v) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+      base[q * stride] = make_uint4(v.l[4 * q], v.l[4 * q + 1], v.l[4 * q + 2], v.l[4 * q + 3]);
+  }
+  __device__ static __forceinline__ void lds_load(const uint4* base, int stride, Fe& v) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      uint4 t = base[q * stride];
+      v.l[4 * q] = t.x;
+      v.l[4 * q + 1] = t.y;
+      v.l[4 * q + 2] = t.z;
+      v.l[4 * q + 3] = t.w;
+    }
+  }
+  static const uint32_t* host_ark(int width, bool d) {
+    return width == 2 ? (d ? F::ArkD21 : F::ArkC21) : (d ? F::ArkD43 : F::ArkC43);
+  }
+};
+
 }  // namespace anemoi

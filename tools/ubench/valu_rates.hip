@@ -125,13 +125,13 @@ int main() {
                   {"mad64 + lshl_add_u64 (pair)", k_mad_lshladd, 2},
                   {"fma_f64 + lshl_add_u64 (pair)", k_fma_lshladd, 2}};
   unsigned long long* d;
-  hipMalloc(&d, sizeof(unsigned long long) * 256 * 16 * 4);
-  printf("%-34s %10s %10s %10s   (shader cycles per wave-instruction, per SIMD = cycles/(n_instr*waves_per_SIMD))\n", "instruction",
-         "1 w/SIMD", "2 w/SIMD", "4 w/SIMD");
+  hipMalloc(&d, sizeof(unsigned long long) * 512 * 16 * 4);
+  printf("%-34s %8s %8s %8s %8s %8s %8s  (s_memtime cycles per wave-instruction per SIMD = dt/(n_instr*waves_per_SIMD))\n",
+         "instruction", "1 w/SIMD", "2", "3", "4", "6", "8");
   for (auto& c : cases) {
     printf("%-34s", c.name);
-    for (int wps : {1, 2, 4}) {
-      const int block = 256 * wps, grid = 256;
+    for (int wps : {1, 2, 3, 4, 6, 8}) {
+      const int per_cu = wps > 4 ? 2 : 1, block = 256 * wps / per_cu, grid = 256 * per_cu;
       std::vector<unsigned long long> h(grid * block / 64);
       for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(c.fn, dim3(grid), dim3(block), 0, 0, d, 12345u, 6789u, 0x9e3779b9u);
       hipDeviceSynchronize();
@@ -139,7 +139,7 @@ int main() {
       std::sort(h.begin(), h.end());
       double med = (double)h[h.size() / 2];
       double n_instr = (double)ITER * BLOCKS_PER_ASM * 8 * c.instr_per_rep;
-      printf(" %10.2f", med / n_instr / wps);
+      printf(" %8.2f", med / n_instr / wps);
     }
     printf("\n");
   }
