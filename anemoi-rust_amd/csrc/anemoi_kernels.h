@@ -20,6 +20,17 @@ namespace anemoi {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: the LDS window table is lane-private
 
+// Register budget: ANEMOI_WAVES waves per SIMD (0 = let the compiler choose).  The multiplier is
+// issue-latency bound, so occupancy is worth more than registers (tools/ubench/valu_rates.hip).
+#ifndef ANEMOI_WAVES
+#define ANEMOI_WAVES 0
+#endif
+#if ANEMOI_WAVES > 0
+#define ANEMOI_KERNEL __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ANEMOI_WAVES, 8)))
+#else
+#define ANEMOI_KERNEL __global__ __launch_bounds__(kBlock)
+#endif
+
 #ifndef ANEMOI_WIN
 #define ANEMOI_WIN 4
 #endif
@@ -102,7 +113,7 @@ __device__ __forceinline__ LdsTable<A> make_table(uint4* lds) {
 // SBOX_ONLY: apply just Anemoi::sbox_layer (src/traits.rs:326-358) -- the unit the reference's
 // test_sbox KATs pin (src/<f>/anemoi_x/mod.rs:68).
 template <int FIELD, int W, bool SBOX_ONLY>
-__global__ __launch_bounds__(kBlock) void k_permutation(uint4* __restrict__ states, size_t n, PermConsts pc) {
+ANEMOI_KERNEL void k_permutation(uint4* __restrict__ states, size_t n, PermConsts pc) {
   using F = FieldC<FIELD>;
   using A = ArithFor<FIELD>;
   constexpr int WIN = KernelCfg<F::N>::WIN, PER = W * A::NABI / 4;
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_permutation(uint4* __restrict__ stat
 
 // out[i] = sum_{j<k} in[i + c*j] + perm(in)[i + c*j], c = W/k  (k = 2: c = W/2 outputs; k = 4: 1 output)
 template <int FIELD, int W, int K>
-__global__ __launch_bounds__(kBlock) void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n,
+ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n,
                                                  PermConsts pc) {
   using F = FieldC<FIELD>;
   using A = ArithFor<FIELD>;
@@ -189,7 +200,7 @@ __device__ __forceinline__ void chunk_to_fe(typename A::Fe& e, const uint8_t* __
 // elements).  Unified rule (== both hasher.rs variants): absorb into state[i]; permute when
 // i == RATE; if num % RATE != 0 absorb a final 1 and permute; digest = state[0].
 template <int FIELD, int W, bool BYTES>
-__global__ __launch_bounds__(kBlock) void k_sponge(const void* __restrict__ src, size_t per_msg, size_t n,
+ANEMOI_KERNEL void k_sponge(const void* __restrict__ src, size_t per_msg, size_t n,
                                                    uint4* __restrict__ out, PermConsts pc) {
   using F = FieldC<FIELD>;
   using A = ArithFor<FIELD>;

@@ -43,28 +43,27 @@ struct Arith29 {
   }
 
   // Montgomery product a*b/R' mod p, result < 2p when (a/p)*(b/p) <= R'/p.  All limbs < 2^29.
+  //
+  // Product scanning, column k:  acc_k = (acc_{k-1} >> 29) + X_k + M_k + m_k p_0  with
+  //   X_k = sum_j a_j b_{k-j}            (no dependence on the reduction digits m)
+  //   M_k = sum_{j<k} m_j p_{k-j}        (only its last term m_{k-1} p_1 waits for the previous column)
+  //   m_k = -(low 29 bits) / p mod 2^29
+  // ANEMOI_ILP >= 1 keeps X_k (and with 2 also the early terms of M_k) in accumulators of their own,
+  // so the serial v_mad_u64_u32 chain through `acc` is only ~5 instructions per column and the
+  // scheduler can overlap the rest (the multiplier is issue-latency bound, not throughput bound).
+#ifndef ANEMOI_ILP
+#define ANEMOI_ILP 2
+#endif
   __device__ static __forceinline__ void mul(Fe& r, const Fe& a, const Fe& b) {
     uint32_t m[NL], out[NL];
     uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < NL; k++) {
+    for (int k = 0; k < 2 * NL - 1; k++) {
+      const int j0 = k < NL ? 0 : k - NL + 1, j1 = k < NL ? k : NL - 1;
+      uint64_t x = 0;
 #pragma unroll
-      for (int j = 0; j <= k; j++) acc += (uint64_t)a.l[j] * b.l[k - j];
-#pragma unroll
-      for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * F::P29[k - j];
-      m[k] = ((uint32_t)acc * F::kN0Inv29) & MASK;
-      acc += (uint64_t)m[k] * F::P29[0];
-      acc >>= 29;
-    }
-#pragma unroll
-    for (int k = NL; k < 2 * NL - 1; k++) {
-#pragma unroll
-      for (int j = k - NL + 1; j < NL; j++) {
-        acc += (uint64_t)a.l[j] * b.l[k - j];
-        acc += (uint64_t)m[j] * F::P29[k - j];
-      }
-      out[k - NL] = (uint32_t)acc & MASK;
-      acc >>= 29;
+      for (int j = j0; j <= j1; j++) x += (uint64_t)a.l[j] * b.l[k - j];
+      column_tail(acc, x, m, out, k);
     }
     out[NL - 1] = (uint32_t)acc;
 #pragma unroll
@@ -81,24 +80,39 @@ struct Arith29 {
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
       const int j0 = k < NL ? 0 : k - NL + 1;
+      uint64_t x = 0;
 #pragma unroll
-      for (int j = j0; j < k - j; j++) acc += (uint64_t)a2[j] * a.l[k - j];
-      if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
-      if (k < NL) {
-#pragma unroll
-        for (int j = 0; j < k; j++) acc += (uint64_t)m[j] * F::P29[k - j];
-        m[k] = ((uint32_t)acc * F::kN0Inv29) & MASK;
-        acc += (uint64_t)m[k] * F::P29[0];
-      } else {
-#pragma unroll
-        for (int j = k - NL + 1; j < NL; j++) acc += (uint64_t)m[j] * F::P29[k - j];
-        out[k - NL] = (uint32_t)acc & MASK;
-      }
-      acc >>= 29;
+      for (int j = j0; j < k - j; j++) x += (uint64_t)a2[j] * a.l[k - j];
+      if ((k & 1) == 0) x += (uint64_t)a.l[k / 2] * a.l[k / 2];
+      column_tail(acc, x, m, out, k);
     }
     out[NL - 1] = (uint32_t)acc;
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = out[i];
+  }
+
+  // reduction half of column k (shared by mul and sqr); x = the column's product sum
+  __device__ static __forceinline__ void column_tail(uint64_t& acc, uint64_t x, uint32_t (&m)[NL], uint32_t (&out)[NL],
+                                                     const int k) {
+    const int j0 = k < NL ? 0 : k - NL + 1, j1 = k < NL ? k - 1 : NL - 1;  // m_j p_{k-j}, j in [j0, j1]
+#if ANEMOI_ILP >= 2
+    uint64_t early = x;
+#pragma unroll
+    for (int j = j0; j < j1; j++) early += (uint64_t)m[j] * F::P29[k - j];
+    acc += early;
+    if (j1 >= j0) acc += (uint64_t)m[j1] * F::P29[k - j1];
+#else
+    acc += x;
+#pragma unroll
+    for (int j = j0; j <= j1; j++) acc += (uint64_t)m[j] * F::P29[k - j];
+#endif
+    if (k < NL) {
+      m[k] = ((uint32_t)acc * F::kN0Inv29) & MASK;
+      acc += (uint64_t)m[k] * F::P29[0];
+    } else {
+      out[k - NL] = (uint32_t)acc & MASK;
+    }
+    acc >>= 29;
   }
 
   // r = a + b (no reduction; the caller keeps values < 2^12 p, see anemoi_perm.h)
