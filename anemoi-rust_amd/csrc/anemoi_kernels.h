@@ -41,7 +41,8 @@ struct KernelCfg {
 
 template <class A, int WIN>
 constexpr size_t lds_table_bytes() {
-  return size_t((1 << (WIN - 1)) - 1) * A::NQ * 16 * kBlock;  // x^3, x^5, ..: x itself stays in VGPRs
+  // x^3, x^5, ..: x itself stays in VGPRs (ANEMOI_PARK: x and y are parked in two more slots)
+  return size_t((1 << (WIN - 1)) - 1 + (ANEMOI_PARK ? 2 : 0)) * A::NQ * 16 * kBlock;
 }
 
 template <class A, int WIN, int W>

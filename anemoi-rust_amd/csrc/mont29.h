@@ -54,6 +54,9 @@ struct Arith29 {
 #ifndef ANEMOI_ILP
 #define ANEMOI_ILP 2
 #endif
+#ifndef ANEMOI_NO_A2
+#define ANEMOI_NO_A2 0
+#endif
   __device__ static __forceinline__ void mul(Fe& r, const Fe& a, const Fe& b) {
     uint32_t m[NL], out[NL];
     uint64_t acc = 0;
@@ -73,16 +76,26 @@ struct Arith29 {
   // Montgomery square.  Off-diagonal products use a pre-doubled copy of a (limb-wise doubling is
   // exact with unsaturated limbs: 2*l[i] < 2^30), so each costs one multiply-accumulate.
   __device__ static __forceinline__ void sqr(Fe& r, const Fe& a) {
-    uint32_t m[NL], out[NL], a2[NL];
+    uint32_t m[NL], out[NL];
+#if !ANEMOI_NO_A2
+    uint32_t a2[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
+#endif
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
       const int j0 = k < NL ? 0 : k - NL + 1;
       uint64_t x = 0;
+#if ANEMOI_NO_A2
+      // register-lean form: sum the off-diagonal products once, double the sum (one v_lshl_add_u64)
+#pragma unroll
+      for (int j = j0; j < k - j; j++) x += (uint64_t)a.l[j] * a.l[k - j];
+      x <<= 1;
+#else
 #pragma unroll
       for (int j = j0; j < k - j; j++) x += (uint64_t)a2[j] * a.l[k - j];
+#endif
       if ((k & 1) == 0) x += (uint64_t)a.l[k / 2] * a.l[k / 2];
       column_tail(acc, x, m, out, k);
     }

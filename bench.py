@@ -51,6 +51,19 @@ def synth_states(n, seed):
     return st
 
 
+def usable_cores():
+    """Host threads this process may really use: the CPU affinity capped by the cgroup quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    # a 1-GPU box grants this job a 16-CPU share of the host whatever the affinity mask says
+    return max(1, min(cores, int(os.environ.get("ANEMOI_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(budget_s=12.0):
     """Oracle timed on a bounded sample of the same workload (rank 0, N = 1)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -61,8 +74,7 @@ def cpu_baseline(budget_s=12.0):
     except Exception:
         path = None
     oracle = orc.Oracle(path)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 256))
+    cores = usable_cores()
     st = synth_states(64 * cores, 0xC0)
     t0 = time.perf_counter()
     oracle.compress_batch(0, WIDTH, st, threads=cores)
