@@ -123,14 +123,12 @@ ANEMOI_KERNEL void k_permutation(uint4* __restrict__ states, size_t n, PermConst
   const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
   block_load<PER>(lds, states, blk0, cnt);
   typename A::Fe st[W];
-#pragma unroll
-  for (int i = 0; i < W; i++) lds_get<A>(lds, threadIdx.x * W + i, st[i]);
+  static_for<0, W>([&](auto i) { lds_get<A>(lds, threadIdx.x * W + i, st[i]); });
   __syncthreads();
   if (SBOX_ONLY) sbox_layer<F, A, W, WIN>(st, pc, make_table<A>(lds));
   else permutation<F, A, W, WIN>(st, pc, make_table<A>(lds));
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < W; i++) lds_put<A>(lds, threadIdx.x * W + i, st[i]);
+  static_for<0, W>([&](auto i) { lds_put<A>(lds, threadIdx.x * W + i, st[i]); });
   block_store<PER>(lds, states, blk0, cnt);
 }
 
@@ -146,8 +144,7 @@ ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out,
   const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
   block_load<PER>(lds, in, blk0, cnt);
   typename A::Fe st[W], sum[C];
-#pragma unroll
-  for (int i = 0; i < W; i++) lds_get<A>(lds, threadIdx.x * W + i, st[i]);
+  static_for<0, W>([&](auto i) { lds_get<A>(lds, threadIdx.x * W + i, st[i]); });
   __syncthreads();
   permutation<F, A, W, WIN>(st, pc, make_table<A>(lds));
 #pragma unroll
@@ -160,16 +157,14 @@ ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out,
   // being held in 12-28 VGPRs across the whole permutation
   __syncthreads();
   block_load<PER>(lds, in, blk0, cnt);
-#pragma unroll
-  for (int i = 0; i < W; i++) lds_get<A>(lds, threadIdx.x * W + i, st[i]);
+  static_for<0, W>([&](auto i) { lds_get<A>(lds, threadIdx.x * W + i, st[i]); });
 #pragma unroll
   for (int i = 0; i < C; i++) {
 #pragma unroll
     for (int j = 0; j < K; j++) A::add(sum[i], sum[i], st[i + C * j]);
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < C; i++) lds_put<A>(lds, threadIdx.x * C + i, sum[i]);
+  static_for<0, C>([&](auto i) { lds_put<A>(lds, threadIdx.x * C + i, sum[i]); });
   block_store<C * A::NABI / 4>(lds, out, blk0, cnt);
 }
 
@@ -214,8 +209,7 @@ ANEMOI_KERNEL void k_sponge(const void* __restrict__ src, size_t per_msg, size_t
   const size_t total = num + (num % RATE == 0 ? 0 : 1);
   const uint8_t* msg = (const uint8_t*)src + (BYTES ? item * per_msg : item * per_msg * A::NABI * 4);
   typename A::Fe st[W];
-#pragma unroll
-  for (int i = 0; i < W; i++) A::set_zero(st[i]);
+  static_for<0, W>([&](auto i) { A::set_zero(st[i]); });
   int pos = 0;
   const LdsTable<A> tab = make_table<A>(lds);
 #pragma nounroll

@@ -28,10 +28,26 @@
 
 namespace anemoi {
 
-// 6-limb fields (BLS12-381 / BLS12-377) run on 29-bit unsaturated limbs; the 4-limb fields stay on
-// 32-bit limbs this round (their R'/p headroom is only 2^6..2^9).
+// Compile-time loop over state elements: bodies that inline a whole Montgomery product are too big
+// for `#pragma unroll`, and a rolled loop would index the register-resident state dynamically
+// (scratch memory).
+template <int I, int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& fn) {
+  if constexpr (I < N) {
+    fn(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(fn);
+  }
+}
+
+// Every field runs on 29-bit unsaturated limbs (14 limbs for 381/377 bits, 9 for 253..255 bits).
+// ANEMOI_ARITH32_FIELDS (a bit mask of field ids) keeps selected fields on the 32-bit-limb path
+// for A/B runs.
+#ifndef ANEMOI_ARITH32_FIELDS
+#define ANEMOI_ARITH32_FIELDS 0
+#endif
 template <int FIELD>
-using ArithFor = std::conditional_t<FieldC<FIELD>::L64 == 6, Arith29<FieldC<FIELD>>, Arith32<FieldC<FIELD>>>;
+using ArithFor = std::conditional_t<((ANEMOI_ARITH32_FIELDS >> FIELD) & 1) == 0, Arith29<FieldC<FIELD>>,
+                                    Arith32<FieldC<FIELD>>>;
 
 // Per-lane window table in LDS: entries 1.. = x^3, x^5, ...; entry e, slot q of this lane at
 // base[((e-1) * NQ + q) * stride].
@@ -80,14 +96,24 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
     A::emul(t, t, x2);
     tab.store(i, t);
   }
+#if ANEMOI_PARK
   tab.load(pc.first == 0 ? E : pc.first, acc);
+#else
+  if (pc.first == 0) acc = x;
+  else tab.load(pc.first, acc);
+#endif
 #pragma nounroll
   for (int s = 0; s < pc.steps; s++) {
     const int nsq = pc.sched[2 * s], idx = pc.sched[2 * s + 1];
 #pragma nounroll
     for (int q = 0; q < nsq; q++) A::esqr(acc, acc);
     if (idx != 255) {
+#if ANEMOI_PARK
       tab.load(idx == 0 ? E : idx, t);
+#else
+      if (idx == 0) t = x;
+      else tab.load(idx, t);
+#endif
       A::emul(acc, acc, t);
     }
   }
@@ -96,9 +122,13 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
 }
 
 // Flystel S-box on one column (src/traits.rs:326-358).
-// Loose bounds (units of p), entering with x, y < 2 after settle():
-//   u = g*y^2 < 2g <= 30 ; x' = x + 64p - u < 66 ; t = x'^(1/alpha) < 2 ; y' = y + 64p - t < 66 ;
-//   x'' = x' + g*y'^2 + delta < 66 + 30 + 1 = 97.   (all far below 2^12, the multiplier's limit)
+// Loose bounds (units of p), entering with x, y < 2 after settle(); a Montgomery product of inputs
+// < A p and < B p is < (A B / H + 1) p with H = R'/p:
+//   381/377-bit fields (H >= 2^25, g*x by limb-wise scaling, subtraction pads with 64 p):
+//     u = g*y^2 < 2g <= 30 ; x' = x + 64p - u < 66 ; t = x'^(1/alpha) < 2 ; y' = y + 64p - t < 66 ;
+//     x'' = x' + g*y'^2 + delta < 66 + 30 + 1 = 97          (every product has A B <= 66^2 << H)
+//   253..255-bit fields (H >= 70, "tight": g*x is a Montgomery product < 2p, subtraction pads with 4 p):
+//     u < 2 ; x' < 6 ; squarings of x', y' have A B = 36 <= H ; t < 2 ; y' < 6 ; x'' < 6 + 2 + 1 = 9
 template <class F, class A, int WIN>
 __device__ __forceinline__ void flystel(typename A::Fe& x, typename A::Fe& y, const PermConsts& pc,
                                         const LdsTable<A>& tab) {
@@ -123,9 +153,11 @@ __device__ __forceinline__ void flystel(typename A::Fe& x, typename A::Fe& y, co
 }
 
 // Linear layer (src/traits.rs:136-157).
-// Loose bounds: W=2 entering < 98: y < 196, x < 294.  W=4, g <= 15, entering < 98:
+// Loose bounds, big-H fields: W=2 entering < 98: y < 196, x < 294.  W=4, g <= 15, entering < 98:
 // x0 < 98+15*98 = 1568, x1 < 98+15*1568 < 2^15, same for y; after the PHT step < 2^17 -- additions
-// only, then settle() (valid for inputs < 2^25 p).
+// only, then settle() (valid for inputs < H p = 2^25 p).
+// Tight fields, entering < 10: W=2: y < 17+.., x < 27 -> settle (27/70 + 1 < 2).  W=4: g*x < 2, so
+// x0, x1 < 12, y2, y3 < 9, PHT: < 21, < 33 -> settle (33/70 + 1 < 2); all values < 2^261.
 template <class F, class A, int W>
 __device__ __forceinline__ void mds_layer(typename A::Fe (&st)[W]) {
   if (W == 2) {
@@ -149,10 +181,7 @@ __device__ __forceinline__ void mds_layer(typename A::Fe (&st)[W]) {
     A::add(st[0], st[0], st[2]);
     A::add(st[1], st[1], st[3]);
   }
-  if (A::kLoose) {
-#pragma unroll
-    for (int i = 0; i < W; i++) A::settle(st[i]);
-  }
+  if (A::kLoose) static_for<0, W>([&](auto i) { A::settle(st[i]); });
 }
 
 template <class A>
@@ -178,11 +207,10 @@ __device__ __forceinline__ void permutation(typename A::Fe (&st)[W], const PermC
   constexpr int R = W == 2 ? F::kRounds21 : F::kRounds43;
 #pragma nounroll
   for (int r = 0; r < R; r++) {
-#pragma unroll
-    for (int i = 0; i < C; i++) {
+    static_for<0, C>([&](auto i) {
       add_global<A>(st[i], pc.ark_c + (r * C + i) * A::NL);
       add_global<A>(st[C + i], pc.ark_d + (r * C + i) * A::NL);
-    }
+    });
     mds_layer<F, A, W>(st);
     sbox_layer<F, A, W, WIN>(st, pc, tab);
   }

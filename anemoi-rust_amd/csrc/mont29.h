@@ -63,7 +63,11 @@ struct Arith29 {
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
       const int j0 = k < NL ? 0 : k - NL + 1, j1 = k < NL ? k : NL - 1;
+#if ANEMOI_ILP < 0
+      uint64_t& x = acc;  // single accumulator: products go straight into the column sum
+#else
       uint64_t x = 0;
+#endif
 #pragma unroll
       for (int j = j0; j <= j1; j++) x += (uint64_t)a.l[j] * b.l[k - j];
       column_tail(acc, x, m, out, k);
@@ -86,7 +90,11 @@ struct Arith29 {
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
       const int j0 = k < NL ? 0 : k - NL + 1;
+#if ANEMOI_ILP < 0 && !ANEMOI_NO_A2
+      uint64_t& x = acc;
+#else
       uint64_t x = 0;
+#endif
 #if ANEMOI_NO_A2
       // register-lean form: sum the off-diagonal products once, double the sum (one v_lshl_add_u64)
 #pragma unroll
@@ -115,7 +123,9 @@ struct Arith29 {
     acc += early;
     if (j1 >= j0) acc += (uint64_t)m[j1] * F::P29[k - j1];
 #else
+#if ANEMOI_ILP >= 0 || ANEMOI_NO_A2
     acc += x;
+#endif
 #pragma unroll
     for (int j = j0; j <= j1; j++) acc += (uint64_t)m[j] * F::P29[k - j];
 #endif
@@ -150,14 +160,25 @@ struct Arith29 {
     norm(r);
   }
 
+  // Fields with little headroom (R'/p < 2^12: the 254/255-bit ones on 9 limbs) keep every value
+  // below ~33 p: there g*x is a Montgomery product by g*R' (result < 2p) and subtraction pads with 4p.
+  static constexpr bool kTight = F::kH29 < 4096.0;
+
   // r = g * x for the small generator g (mul_by_generator, src/traits.rs:78-91)
   __device__ static __forceinline__ void mul_g(Fe& r, const Fe& x) {
-    uint64_t acc = 0;
+    if constexpr (kTight) {
+      Fe g;
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-      acc += (uint64_t)x.l[i] * (uint32_t)F::kG;
-      r.l[i] = (uint32_t)acc & MASK;
-      acc >>= 29;
+      for (int i = 0; i < NL; i++) g.l[i] = F::GMont29[i];
+      mul(r, x, g);
+    } else {
+      uint64_t acc = 0;
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        acc += (uint64_t)x.l[i] * (uint32_t)F::kG;
+        r.l[i] = (uint32_t)acc & MASK;
+        acc >>= 29;
+      }
     }
   }
 
@@ -193,15 +214,16 @@ struct Arith29 {
     for (int i = 0; i < NL; i++) x.l[i] = borrow ? x.l[i] : d[i];
   }
 
-  // 32-bit words (plain integer) -> 29-bit limbs (same integer)
+  // 32-bit words (plain integer) -> 29-bit limbs (same integer).  32-bit funnel shifts only
+  // (v_alignbit_b32): a 64-bit formulation makes hipcc build the value through scratch memory.
   __device__ static __forceinline__ void repack_in(Fe& r, const uint32_t (&w)[NABI]) {
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const int bit = 29 * i, lo = bit >> 5, sh = bit & 31;
-      uint64_t v = 0;
-      if (lo < NABI) v = w[lo];
-      if (lo + 1 < NABI) v |= (uint64_t)w[lo + 1] << 32;
-      r.l[i] = (uint32_t)(v >> sh) & MASK;
+      const uint32_t wl = lo < NABI ? w[lo] : 0u;
+      const uint32_t wh = lo + 1 < NABI ? w[lo + 1] : 0u;
+      const uint32_t v = sh == 0 ? wl : ((wl >> sh) | (wh << (32 - sh)));
+      r.l[i] = v & MASK;
     }
   }
   // 29-bit limbs (value < 2^(32 NABI)) -> 32-bit words
@@ -209,10 +231,10 @@ struct Arith29 {
 #pragma unroll
     for (int j = 0; j < NABI; j++) {
       const int bit = 32 * j, i0 = bit / 29, off = bit - 29 * i0;
-      uint64_t v = (uint64_t)a.l[i0] >> off;
-      if (i0 + 1 < NL) v |= (uint64_t)a.l[i0 + 1] << (29 - off);
-      if (i0 + 2 < NL && 58 - off < 32) v |= (uint64_t)a.l[i0 + 2] << (58 - off);
-      w[j] = (uint32_t)v;
+      uint32_t v = a.l[i0] >> off;                                  // 29 - off bits
+      if (i0 + 1 < NL) v |= a.l[i0 + 1] << (29 - off);              // next 29 bits
+      if (i0 + 2 < NL && 58 - off < 32) v |= a.l[i0 + 2] << (58 - off);
+      w[j] = v;
     }
   }
 

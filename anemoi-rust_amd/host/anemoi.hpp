@@ -1,0 +1,185 @@
+// anemoi.hpp -- C++ host-side mirror of the reference crate's operator surface for this path,
+// implemented on the C-ABI of libanemoi_mi355x.so (include/anemoi_mi355x.h).
+//
+// The reference is Rust; no Rust toolchain exists in the build image, so the host layer above the
+// C-ABI is written in C++ with the reference's names, argument meaning and error behaviour
+// (INTEGRATION.md shows the equivalent Rust `-sys` shim):
+//
+//   reference (src/traits.rs:8-33, src/<field>/anemoi_X_Y/{mod,hasher,digest}.rs)   here
+//   ------------------------------------------------------------------------------  ---------------------------
+//   pub struct AnemoiBls12_381_2_1; impl Sponge<Felt> + impl Jive<Felt>               anemoi::AnemoiBls12_381_2_1
+//   Sponge::hash(&[u8]) / hash_field(&[Felt]) / merge(&[Digest; 2])                   ::hash / ::hash_field / ::merge
+//   Jive::compress(&[Felt]) -> Vec<Felt> / compress_k(&[Felt], k)                     ::compress / ::compress_k
+//   STATE_WIDTH, RATE_WIDTH, NUM_COLUMNS, DIGEST_SIZE, NUM_HASH_ROUNDS                same-named constants
+//   AnemoiDigest::{new, as_elements, to_elements, digests_to_elements, to_bytes}      anemoi::Digest<F>
+//   assert!(..) panics (hasher.rs:97,107; 4-3: :149,163-165)                          throw std::invalid_argument
+//
+// plus the batched forms a GPU needs (compress_batch, hash_batch, ...), which equal the single-item
+// functions applied to every item.  `Felt` is the arkworks in-memory form (Montgomery limbs).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/anemoi_mi355x.h"
+
+namespace anemoi {
+
+struct DeviceError : std::runtime_error {
+  int code;
+  DeviceError(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+inline void check(int rc) {
+  if (rc == ANEMOI_OK) return;
+  std::string msg = std::string("anemoi_mi355x: ") + anemoi_strerror(rc);
+  if (rc == ANEMOI_ERR_ARG) throw std::invalid_argument(msg);  // the reference's assert! panics
+  if (rc == ANEMOI_ERR_DEVICE) msg += std::string(" (") + anemoi_last_error() + ")";
+  throw DeviceError(rc, msg);
+}
+
+template <int LIMBS>
+struct Felt {  // = arkworks Fp<MontBackend<_, LIMBS>, LIMBS>: little-endian u64 limbs, Montgomery form
+  std::array<uint64_t, LIMBS> limbs{};
+  bool operator==(const Felt& o) const { return limbs == o.limbs; }
+  bool operator!=(const Felt& o) const { return !(*this == o); }
+};
+
+// src/<field>/anemoi_X_Y/digest.rs: AnemoiDigest([Felt; DIGEST_SIZE]), DIGEST_SIZE = 1
+template <int FIELD, int LIMBS>
+struct Digest {
+  static constexpr size_t DIGEST_SIZE = 1;
+  std::array<Felt<LIMBS>, 1> elements{};
+  Digest() = default;
+  explicit Digest(const std::array<Felt<LIMBS>, 1>& e) : elements(e) {}
+  const std::array<Felt<LIMBS>, 1>& as_elements() const { return elements; }
+  std::array<Felt<LIMBS>, 1> to_elements() const { return elements; }
+  static std::array<Felt<LIMBS>, 2> digests_to_elements(const std::array<Digest, 2>& d) {
+    return {d[0].elements[0], d[1].elements[0]};
+  }
+  // digest.rs:42-46: serialize_compressed = canonical little-endian bytes (32 or 48)
+  std::array<uint8_t, 8 * LIMBS> to_bytes(int device = 0) const {
+    std::array<uint64_t, LIMBS> canon{};
+    check(anemoi_from_montgomery(FIELD, elements[0].limbs.data(), canon.data(), 1, device));
+    std::array<uint8_t, 8 * LIMBS> out{};
+    for (int i = 0; i < LIMBS; i++)
+      for (int b = 0; b < 8; b++) out[8 * i + b] = uint8_t(canon[i] >> (8 * b));
+    return out;
+  }
+  bool operator==(const Digest& o) const { return elements == o.elements; }
+};
+
+template <int FIELD, int WIDTH, int LIMBS, int ROUNDS>
+struct Instance {
+  using F = Felt<LIMBS>;
+  using D = Digest<FIELD, LIMBS>;
+  static constexpr size_t STATE_WIDTH = WIDTH;
+  static constexpr size_t RATE_WIDTH = WIDTH - 1;
+  static constexpr size_t NUM_COLUMNS = WIDTH / 2;
+  static constexpr size_t DIGEST_SIZE = 1;
+  static constexpr size_t NUM_HASH_ROUNDS = ROUNDS;
+
+  // ---- Jive (src/traits.rs:23-33) --------------------------------------------------------------
+  static std::vector<F> compress(const std::vector<F>& elems, int device = 0) {
+    if (elems.size() != STATE_WIDTH) throw std::invalid_argument("compress: elems.len() != STATE_WIDTH");
+    return compress_batch(elems, device);
+  }
+  static std::vector<F> compress_k(const std::vector<F>& elems, size_t k, int device = 0) {
+    if (elems.size() != STATE_WIDTH) throw std::invalid_argument("compress_k: elems.len() != STATE_WIDTH");
+    return compress_k_batch(elems, k, device);
+  }
+  // ---- Sponge (src/traits.rs:8-20) -------------------------------------------------------------
+  static D hash(const uint8_t* bytes, size_t len, int device = 0) {
+    D d;
+    check(anemoi_hash_bytes_batch(FIELD, WIDTH, bytes, len, 1, d.elements[0].limbs.data(), device));
+    return d;
+  }
+  static D hash(const std::vector<uint8_t>& bytes, int device = 0) { return hash(bytes.data(), bytes.size(), device); }
+  static D hash_field(const std::vector<F>& elems, int device = 0) {
+    D d;
+    check(anemoi_hash_field_batch(FIELD, WIDTH, elems.empty() ? nullptr : elems[0].limbs.data(), elems.size(), 1,
+                                  d.elements[0].limbs.data(), device));
+    return d;
+  }
+  static D merge(const std::array<D, 2>& digests, int device = 0) {
+    D d;
+    if (WIDTH == 2) {  // anemoi_2_1/hasher.rs:87-92: Jive compression of the two digests
+      auto e = D::digests_to_elements(digests);
+      check(anemoi_merge_batch(FIELD, e[0].limbs.data(), d.elements[0].limbs.data(), 1, device));
+    } else {
+      // anemoi_4_3/hasher.rs:131-145 writes digests[0] into BOTH rate cells (line :138 reads
+      // digests[0] again); kept bit-for-bit, on top of the batched permutation
+      std::array<F, 4> st{};
+      st[0] = digests[0].elements[0];
+      st[1] = digests[0].elements[0];
+      check(anemoi_permutation_batch(FIELD, WIDTH, st[0].limbs.data(), 1, device));
+      d.elements[0] = st[0];
+    }
+    return d;
+  }
+
+  // ---- batched forms (new surface; item i of the result == the single-item function on item i) ---
+  static std::vector<F> compress_k_batch(const std::vector<F>& states, size_t k, int device = 0) {
+    if (states.size() % STATE_WIDTH) throw std::invalid_argument("compress_batch: not a whole number of states");
+    if (k == 0 || STATE_WIDTH % k) throw std::invalid_argument("compress_k: STATE_WIDTH % k != 0");
+    const size_t n = states.size() / STATE_WIDTH;
+    std::vector<F> out(n * (STATE_WIDTH / k));
+    check(anemoi_jive_compress_k_batch(FIELD, WIDTH, int(k), n ? states[0].limbs.data() : nullptr,
+                                       n ? out[0].limbs.data() : nullptr, n, device));
+    return out;
+  }
+  static std::vector<F> compress_batch(const std::vector<F>& states, int device = 0) {
+    return compress_k_batch(states, 2, device);
+  }
+  static void permutation_batch(std::vector<F>& states, int device = 0) {
+    if (states.size() % STATE_WIDTH) throw std::invalid_argument("permutation_batch: not a whole number of states");
+    check(anemoi_permutation_batch(FIELD, WIDTH, states.empty() ? nullptr : states[0].limbs.data(),
+                                   states.size() / STATE_WIDTH, device));
+  }
+  static std::vector<D> hash_batch(const uint8_t* msgs, size_t msg_len, size_t n, int device = 0) {
+    std::vector<D> out(n);
+    static_assert(sizeof(D) == sizeof(uint64_t) * LIMBS, "Digest must be layout-compatible with one element");
+    check(anemoi_hash_bytes_batch(FIELD, WIDTH, msgs, msg_len, n, n ? out[0].elements[0].limbs.data() : nullptr, device));
+    return out;
+  }
+  static D merkle_root(const std::vector<D>& leaves, unsigned depth, int device = 0) {
+    static_assert(WIDTH == 2, "the Merkle driver uses the 2-1 instance's merge");
+    if (leaves.size() != (size_t(1) << depth)) throw std::invalid_argument("merkle_root: need 2^depth leaves");
+    D root;
+    check(anemoi_merkle_root(FIELD, leaves[0].elements[0].limbs.data(), depth, root.elements[0].limbs.data(), device));
+    return root;
+  }
+
+  // canonical integers (little-endian u64 limbs) <-> Felt, e.g. for MontFp!-style constants
+  static F from_canonical(const std::array<uint64_t, LIMBS>& c, int device = 0) {
+    F f;
+    check(anemoi_to_montgomery(FIELD, c.data(), f.limbs.data(), 1, device));
+    return f;
+  }
+  static std::array<uint64_t, LIMBS> to_canonical(const F& f, int device = 0) {
+    std::array<uint64_t, LIMBS> c{};
+    check(anemoi_from_montgomery(FIELD, f.limbs.data(), c.data(), 1, device));
+    return c;
+  }
+};
+
+// the reference's 14 unit structs (src/<field>/anemoi_X_Y/mod.rs:37-38); rounds from :31
+using AnemoiBls12_381_2_1 = Instance<ANEMOI_BLS12_381, 2, 6, 21>;
+using AnemoiBls12_381_4_3 = Instance<ANEMOI_BLS12_381, 4, 6, 14>;
+using AnemoiBls12_377_2_1 = Instance<ANEMOI_BLS12_377, 2, 6, 21>;
+using AnemoiBls12_377_4_3 = Instance<ANEMOI_BLS12_377, 4, 6, 14>;
+using AnemoiBn254_2_1 = Instance<ANEMOI_BN_254, 2, 4, 21>;
+using AnemoiBn254_4_3 = Instance<ANEMOI_BN_254, 4, 4, 14>;
+using AnemoiEdOnBls12_377_2_1 = Instance<ANEMOI_ED_ON_BLS12_377, 2, 4, 19>;
+using AnemoiEdOnBls12_377_4_3 = Instance<ANEMOI_ED_ON_BLS12_377, 4, 4, 13>;
+using AnemoiJubjub_2_1 = Instance<ANEMOI_JUBJUB, 2, 4, 21>;
+using AnemoiJubjub_4_3 = Instance<ANEMOI_JUBJUB, 4, 4, 14>;
+using AnemoiPallas_2_1 = Instance<ANEMOI_PALLAS, 2, 4, 21>;
+using AnemoiPallas_4_3 = Instance<ANEMOI_PALLAS, 4, 4, 14>;
+using AnemoiVesta_2_1 = Instance<ANEMOI_VESTA, 2, 4, 21>;
+using AnemoiVesta_4_3 = Instance<ANEMOI_VESTA, 4, 4, 14>;
+
+}  // namespace anemoi

@@ -111,6 +111,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import anemoi_amd as A  # after torch: binds to the same HIP runtime
+    from anemoi_amd.shard import max_over_ranks
     fid = A.field_id(FIELD)
     n = 1 << args.batch_log2
     dev = torch.device("cuda", local_rank)
@@ -142,9 +143,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist, dev)
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
 
     # spot-check the timed output against the C-ABI's own single-item path is the tests' job; here only

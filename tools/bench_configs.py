@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Times every BASELINE.json config shape on ONE GPU (inputs resident in HBM, HIP events on the launch
+stream).  Not the driver's bench (that is bench.py = config 2); this fills the per-row measurements
+of DESIGN.md / profiles/README.md.
+    python tools/bench_configs.py [--lib path.so] [--quick]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=os.path.join(ROOT, "anemoi-rust_amd", "lib", "libanemoi_mi355x.so"))
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    lib = ctypes.CDLL(os.path.abspath(args.lib))
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.anemoi_jive_compress_k_dev.argtypes = [ci, ci, ci, vp, vp, sz, vp]
+    lib.anemoi_hash_bytes_dev.argtypes = [ci, ci, vp, sz, sz, vp, vp]
+    lib.anemoi_merkle_root_dev.argtypes = [ci, vp, ctypes.c_uint, vp, vp, vp]
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream()
+    rng = np.random.default_rng(7)
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            fn()
+            b.record(stream)
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return sorted(ts)[len(ts) // 2]
+
+    def states(n, width, limbs):
+        h = rng.integers(0, 1 << 60, size=(n, width, limbs), dtype=np.uint64)  # limbs < 2^60 => element < p
+        return torch.from_numpy(h.view(np.int64).reshape(-1)).to(dev)
+
+    out = {}
+
+    def jive(name, field, width, limbs, n, modmul):
+        d_in, d_out = states(n, width, limbs), torch.empty(n * limbs * (width // 2), dtype=torch.int64, device=dev)
+        ms = timed(lambda: check(lib.anemoi_jive_compress_k_dev(field, width, 2, d_in.data_ptr(), d_out.data_ptr(), n,
+                                                                stream.cuda_stream)))
+        out[name] = {"ms": ms, "compress_per_s": n / ms * 1e3, "modmul_per_s": n * modmul / ms * 1e3,
+                     "algorithmic_GBps": n * limbs * 8 * (width + width // 2) / ms / 1e6}
+
+    def check(rc):
+        assert rc == 0, rc
+
+    jive("cfg1_vesta_2_1_x1024", 6, 2, 4, 1024, 6195)
+    jive("cfg2_bls12_381_2_1_x2^20", 0, 2, 6, 1 << 20, 9576)
+    if not args.quick:
+        jive("cfg4_bls12_381_2_1_x2^21_per_gpu", 0, 2, 6, 1 << 21, 9576)
+    jive("extra_jubjub_2_1_x2^20", 4, 2, 4, 1 << 20, 6447)
+    jive("extra_bn254_4_3_x2^20", 2, 4, 4, 1 << 20, 8596)
+    jive("extra_bls12_381_4_3_x2^19", 0, 4, 6, 1 << 19, 12768)
+
+    # config 3: Anemoi-4-3 over BN-254, sponge hash of 10 240-byte messages
+    nmsg = (1 << 13) if args.quick else (1 << 16)
+    msgs = torch.from_numpy(rng.integers(0, 256, size=(nmsg, 10240), dtype=np.uint8)).to(dev)
+    dig = torch.empty(nmsg * 4, dtype=torch.int64, device=dev)
+    ms = timed(lambda: check(lib.anemoi_hash_bytes_dev(2, 4, msgs.data_ptr(), 10240, nmsg, dig.data_ptr(),
+                                                       stream.cuda_stream)), reps=2)
+    out["cfg3_bn254_4_3_sponge_10KB_x2^%d" % (13 if args.quick else 16)] = {
+        "ms": ms, "messages_per_s": nmsg / ms * 1e3, "permutations_per_s": nmsg * 111 / ms * 1e3,
+        "modmul_per_s": nmsg * 954156 / ms * 1e3, "algorithmic_GBps": nmsg * 10272 / ms / 1e6}
+
+    # config 5: Jubjub Merkle tree, one GPU's subtree (depth 21 of the depth-24 tree; 2^21 leaves)
+    depth = 17 if args.quick else 21
+    leaves = states(1 << depth, 1, 4)
+    scratch = torch.empty((1 << depth) * 4, dtype=torch.int64, device=dev)
+    root = torch.empty(4, dtype=torch.int64, device=dev)
+    ms = timed(lambda: check(lib.anemoi_merkle_root_dev(4, leaves.data_ptr(), depth, scratch.data_ptr(), root.data_ptr(),
+                                                        stream.cuda_stream)), reps=2)
+    out["cfg5_jubjub_merkle_depth%d_subtree" % depth] = {
+        "ms": ms, "merges_per_s": ((1 << depth) - 1) / ms * 1e3, "algorithmic_GBps": 96 * ((1 << depth) - 1) / ms / 1e6}
+    for k, v in out.items():
+        print("%-44s %s" % (k, json.dumps({a: (round(b, 3) if b < 1e4 else float("%.4g" % b)) for a, b in v.items()})))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
