@@ -151,6 +151,18 @@ def main():
     assert int(torch.count_nonzero(d_out[: 6 * 64]).item()) > 0
 
     if rank == 0:
+        # HBM traffic and VALU utilisation come from the committed rocprofv3 --pmc passes of this same
+        # command (profiles/rNN/pmc_k_jive.json): counters cannot be read from inside the process.
+        traffic, valu_busy, prof_src = None, None, None
+        try:
+            prof_dirs = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r"))
+            prof_src = os.path.join("profiles", prof_dirs[-1], "pmc_k_jive.json")
+            pmc = json.load(open(os.path.join(ROOT, prof_src)))["derived"]
+            if args.batch_log2 == BATCH_LOG2:
+                traffic = pmc["hbm_traffic_bytes_per_launch"]
+            valu_busy = pmc["valu_busy_fraction"]
+        except Exception:
+            prof_src = None
         total_items = n * world * args.steps
         value = total_items / elapsed
         achieved = BYTES_PER_ITEM * n / (kernel_ms * 1e-3) / 1e9
@@ -163,12 +175,16 @@ def main():
                                    "inputs resident in HBM" % args.batch_log2,
                        "field": FIELD, "state_width": WIDTH, "batch_per_gpu": n, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+                         "traffic_source": prof_src,
                          "kernel": "k_jive<bls12_381,2,2>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_ITEM * n},
-            "alu": {"modmul_per_s": MODMUL_PER_ITEM * n / (kernel_ms * 1e-3),
-                    "note": "384-bit Montgomery mul/sqr per second (reference chain count 9576 per compression); "
-                            "the path is VALU-bound, see DESIGN.md"},
+            "alu": {"bound": "valu", "modmul_per_s": MODMUL_PER_ITEM * n / (kernel_ms * 1e-3),
+                    "valu_busy_frac_profiled": valu_busy,
+                    "note": "384-bit Montgomery mul/sqr per second (reference chain count 9576 per compression). "
+                            "The path is VALU-issue bound: the profiled kernel keeps the vector ALUs busy in "
+                            "valu_busy_frac_profiled of all SIMD cycles (SQ_ACTIVE_INST_VALU, profiles/), see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
