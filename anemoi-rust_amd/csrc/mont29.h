@@ -1,16 +1,17 @@
 // mont29.h -- lane-private Montgomery arithmetic on unsaturated 29-bit limbs for gfx950 (CDNA4).
 //
-// Why not 32-bit limbs: measured on MI355X (tools/ubench/valu_rates.hip, profiles/), a
-// v_mad_u64_u32 costs the same issue time as a v_addc_co_u32 / v_lshl_add_u64 (~3.4 cycles per
-// wave-instruction at 4 waves/SIMD), and a VALU-written carry (VCC/SGPR) needs 2 wait states before
-// a VALU can consume it.  With saturated 32-bit limbs every multiply-accumulate therefore costs a
-// multiply PLUS a carry instruction.  With 29-bit limbs a whole column of the product
+// Why not 32-bit limbs: measured on MI355X (tools/ubench/wall_rates.hip, profiles/r01/), a
+// v_mad_u64_u32 (4.6-5 cycles per wave-instruction per SIMD) costs about the same as a
+// v_addc_co_u32 / v_lshl_add_u64 (4.2-4.4), and a VALU-written carry (VCC/SGPR) needs 2 wait states
+// before a VALU can consume it.  With saturated 32-bit limbs every multiply-accumulate therefore
+// costs a multiply PLUS a carry instruction.  With 29-bit limbs a whole column of the product
 // (<= 28 products < 2^58) fits a 64-bit accumulator, so a multiply-accumulate is exactly ONE
 // v_mad_u64_u32 and carries are resolved once per column (one shift, one mask):
-//     BLS12-381 squaring: 315 multiplies + ~100 cheap ops  vs  234 multiplies + 234 carries + pads.
-// The spare bits also remove every conditional subtraction: R' = 2^(29*NL) exceeds p by >= 2^25 for
-// the 381/377-bit fields, so a Montgomery product of inputs < 2^12 p is < 2p and additions /
-// subtractions need no reduction at all; values are made canonical once, on the way out.
+//     BLS12-381 squaring: 301 multiplies + 111 cheap ops  vs  234 multiplies + 234 carries + pads.
+// The spare bits also remove every conditional subtraction: with H = R'/p (R' = 2^(29*NL); 2^25 for
+// the 381/377-bit fields, 70..438 for the 253..255-bit ones) a Montgomery product of inputs < A p
+// and < B p is < (A B / H + 1) p, so additions / subtractions need no reduction at all and values
+// are made canonical once, on the way out.  The bounds are tracked in anemoi_perm.h.
 //
 // Element form inside the kernels: NL limbs l[i] < 2^29, value = sum l[i] 2^(29 i), Montgomery form
 // with R' = 2^(29 NL).  The C-ABI form (arkworks: 32-bit-limb R = 2^(64 L)) is converted on load

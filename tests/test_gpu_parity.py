@@ -127,6 +127,23 @@ def test_sponge_vs_oracle(A, oracle, params, field, width):
     assert inst.digest_to_bytes(d) == oracle.digest_bytes(fid, d)
 
 
+@pytest.mark.parametrize("field,width", INSTANCES)
+def test_long_sponge_bound_stress(A, oracle, params, field, width):
+    """Many chained permutations per lane (the unsaturated-limb arithmetic keeps values only loosely
+    bounded between reductions): 3 000-byte messages incl. all-0xFF and all-zero ones, and element
+    messages made of p-1, against the oracle."""
+    fid, p, L = FIELD_IDS.index(field), int(params[field]["modulus"]), params[field]["u64_limbs"]
+    inst = A.Anemoi(field, width)
+    rng = np.random.default_rng(99 + fid)
+    msgs = rng.integers(0, 256, size=(6, 3000), dtype=np.uint8)
+    msgs[0] = 0xFF
+    msgs[1] = 0
+    assert (inst.hash_batch(msgs) == oracle.hash_bytes_batch(fid, width, msgs, threads=6)).all()
+    el = np.broadcast_to(oracle.ints_to_mont(fid, [p - 1]), (2, 40, L)).copy()
+    el[1, ::2] = oracle.ints_to_mont(fid, [1])
+    assert (inst.hash_field_batch(el) == oracle.hash_field_batch(fid, width, el, threads=2)).all()
+
+
 @pytest.mark.parametrize("field", FIELD_IDS)
 def test_montgomery_conversion(A, oracle, params, field):
     fid, p, L = FIELD_IDS.index(field), int(params[field]["modulus"]), params[field]["u64_limbs"]
