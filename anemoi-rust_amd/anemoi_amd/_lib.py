@@ -65,6 +65,12 @@ _SIGS = {
     "anemoi_hash_field_batch": ([_int, _int, _u64p, _sz, _sz, _u64p, _int], _int),
     "anemoi_hash_bytes_batch": ([_int, _int, _u8p, _sz, _sz, _u64p, _int], _int),
     "anemoi_merkle_root": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
+    "anemoi_merkle_tree": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
+    "anemoi_merkle_path": ([_int, _u64p, ctypes.c_uint, _sz, _u64p], _int),
+    "anemoi_merkle_verify_batch": ([_int, _u64p, _u64p, _u64p, ctypes.c_uint, _sz, _u64p, _u8p, _int], _int),
+    "anemoi_merkle_root_arity4": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
+    "anemoi_merkle_tree_dev": ([_int, _vp, ctypes.c_uint, _vp, _vp], _int),
+    "anemoi_merkle_climb_dev": ([_int, _vp, _vp, _vp, ctypes.c_uint, _sz, _vp, _vp], _int),
     "anemoi_to_montgomery": ([_int, _u64p, _u64p, _sz, _int], _int),
     "anemoi_from_montgomery": ([_int, _u64p, _u64p, _sz, _int], _int),
     "anemoi_permutation_dev": ([_int, _int, _vp, _sz, _vp], _int),
@@ -238,6 +244,45 @@ class Anemoi:
             raise AnemoiError(-3)
         out = np.empty(self.limbs, dtype=np.uint64)
         _check(lib.anemoi_merkle_root(self.field, _p64(lv), depth, _p64(out), self.device))
+        return out
+
+    def merkle_tree(self, leaves, depth):
+        """All levels: list [level0 (leaves), level1, ..., [root]] of numpy arrays."""
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, self.limbs)
+        if len(lv) != 1 << depth:
+            raise AnemoiError(-3)
+        flat = np.empty(((2 << depth) - 1, self.limbs), dtype=np.uint64)
+        _check(lib.anemoi_merkle_tree(self.field, _p64(lv), depth, _p64(flat), self.device))
+        self._last_tree = flat
+        out, off = [], 0
+        for l in range(depth + 1):
+            out.append(flat[off: off + (1 << (depth - l))])
+            off += 1 << (depth - l)
+        return out
+
+    def merkle_path(self, tree_levels, depth, index):
+        flat = np.ascontiguousarray(np.concatenate(tree_levels), dtype=np.uint64)
+        path = np.empty((depth, self.limbs), dtype=np.uint64)
+        rc = lib.anemoi_merkle_path(self.field, _p64(flat), depth, index, _p64(path) if depth else None)
+        _check(rc)
+        return path
+
+    def merkle_verify_batch(self, leaves, indices, paths, depth, root):
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, self.limbs)
+        ix = np.ascontiguousarray(indices, dtype=np.uint64)
+        pa = np.ascontiguousarray(paths, dtype=np.uint64).reshape(len(lv), depth, self.limbs)
+        rt = np.ascontiguousarray(root, dtype=np.uint64).reshape(self.limbs)
+        ok = np.zeros(len(lv), dtype=np.uint8)
+        _check(lib.anemoi_merkle_verify_batch(self.field, _p64(lv), _p64(ix), _p64(pa) if pa.size else None, depth,
+                                              len(lv), _p64(rt), _p8(ok), self.device))
+        return ok.astype(bool)
+
+    def merkle_root_arity4(self, leaves, depth4):
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, self.limbs)
+        if len(lv) != 1 << (2 * depth4):
+            raise AnemoiError(-3)
+        out = np.empty(self.limbs, dtype=np.uint64)
+        _check(lib.anemoi_merkle_root_arity4(self.field, _p64(lv), depth4, _p64(out), self.device))
         return out
 
     # ---- the reference's single-item surface (src/traits.rs:8-33)

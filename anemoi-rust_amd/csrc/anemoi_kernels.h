@@ -245,6 +245,55 @@ ANEMOI_KERNEL void k_sponge(const void* __restrict__ src, size_t per_msg, size_t
   block_store<A::NABI / 4>(lds, out, blk0, cnt);
 }
 
+// Merkle authentication: lane i hashes leaf i up its path (depth sibling digests, bottom-up) with
+// the 2-1 instance's merge (= Jive compress of [left, right], anemoi_2_1/hasher.rs:87-92) and writes
+// the recomputed root; bit l of index[i] says whether the node is the right child at level l.
+template <int FIELD>
+ANEMOI_KERNEL void k_merkle_climb(const uint4* __restrict__ leaves, const uint64_t* __restrict__ index,
+                                  const uint4* __restrict__ paths, unsigned depth, size_t n, uint4* __restrict__ out,
+                                  PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using A = ArithFor<FIELD>;
+  constexpr int WIN = KernelCfg<F::N>::WIN, Q = A::NABI / 4;
+  extern __shared__ uint4 lds[];
+  const size_t blk0 = size_t(blockIdx.x) * kBlock;
+  const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
+  const size_t item = blk0 + (threadIdx.x < cnt ? threadIdx.x : 0);  // idle lanes redo item blk0
+  const uint64_t idx = index[item];
+  auto load = [&](const uint4* src, typename A::Fe& v) {
+    uint32_t w[A::NABI];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      uint4 x = src[q];
+      w[4 * q] = x.x, w[4 * q + 1] = x.y, w[4 * q + 2] = x.z, w[4 * q + 3] = x.w;
+    }
+    A::from_abi(v, w);
+  };
+  typename A::Fe cur, sib;
+  load(leaves + item * Q, cur);
+  const LdsTable<A> tab = make_table<A>(lds);
+#pragma nounroll
+  for (unsigned l = 0; l < depth; l++) {
+    load(paths + (item * depth + l) * Q, sib);
+    const bool right = (idx >> l) & 1;  // this node is the right child: state = [sibling, node]
+    typename A::Fe st[2], sum;
+#pragma unroll
+    for (int i = 0; i < A::NL; i++) {
+      st[0].l[i] = right ? sib.l[i] : cur.l[i];
+      st[1].l[i] = right ? cur.l[i] : sib.l[i];
+    }
+    A::add(sum, cur, sib);
+    // park the feed-forward sum in the accumulator-free part of the round: it is only 1 element
+    permutation<F, A, 2, WIN>(st, pc, tab);
+    A::add(cur, st[0], st[1]);
+    A::add(cur, cur, sum);
+    if (A::kLoose) A::settle(cur);
+  }
+  __syncthreads();
+  lds_put<A>(lds, threadIdx.x, cur);
+  block_store<Q>(lds, out, blk0, cnt);
+}
+
 // to = true: canonical -> Montgomery (x * R^2 / R); to = false: Montgomery -> canonical (x * 1 / R).
 // Always on 32-bit limbs: this is the ABI's own R = 2^(32 N).
 template <int FIELD>
@@ -284,6 +333,8 @@ struct FieldOps {
   hipError_t (*sponge)(int width, int bytes, const void* d_src, size_t per_msg, size_t n, void* d_out, PermConsts pc,
                        hipStream_t s);
   hipError_t (*mont_convert)(int to, const void* d_in, void* d_out, size_t count, hipStream_t s);
+  hipError_t (*merkle_climb)(const void* d_leaves, const void* d_index, const void* d_paths, unsigned depth, size_t n,
+                             void* d_out, PermConsts pc, hipStream_t s);
 };
 
 const FieldOps* field_ops(int field);  // capi.hip
@@ -363,9 +414,17 @@ struct Launch {
     return hipGetLastError();
   }
 
+  static hipError_t merkle_climb(const void* leaves, const void* index, const void* paths, unsigned depth, size_t n,
+                                 void* out, PermConsts pc, hipStream_t s) {
+    if (!n) return hipSuccess;
+    k_merkle_climb<FIELD><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>(
+        (const uint4*)leaves, (const uint64_t*)index, (const uint4*)paths, depth, n, (uint4*)out, pc);
+    return hipGetLastError();
+  }
+
   static const FieldOps* ops() {
-    static const FieldOps o{F::L64,      F::kChunk,   F::kRounds21, F::kRounds43, F::kName,
-                            host_consts, permutation, jive,         sponge,       mont_convert};
+    static const FieldOps o{F::L64,      F::kChunk,   F::kRounds21, F::kRounds43, F::kName,     host_consts,
+                            permutation, jive,        sponge,       mont_convert, merkle_climb};
     return &o;
   }
 };

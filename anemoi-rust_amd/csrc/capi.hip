@@ -327,6 +327,38 @@ int anemoi_merkle_root_dev(int field, const void* d_leaves, unsigned depth, void
   return merkle_levels_dev(field, d_leaves, depth, d_scratch, d_root, (hipStream_t)stream);
 }
 
+/* levels retained: d_tree = level 0 (2^depth leaves, copied) | level 1 | ... | level depth (root) */
+int anemoi_merkle_tree_dev(int field, const void* d_leaves, unsigned depth, void* d_tree, void* stream) {
+  int rc = check_instance(field, 2);
+  if (rc) return rc;
+  if (!d_leaves || !d_tree || depth > 30) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field);
+  hipStream_t s = (hipStream_t)stream;
+  if (d_tree != d_leaves)
+    HIP_TRY(hipMemcpyAsync(d_tree, d_leaves, (size_t(1) << depth) * eb, hipMemcpyDeviceToDevice, s));
+  PermConsts pc;
+  if ((rc = get_consts(field, 2, &pc))) return rc;
+  char* lvl = (char*)d_tree;
+  for (unsigned l = 0; l < depth; l++) {
+    const size_t n = size_t(1) << (depth - 1 - l);
+    char* next = lvl + 2 * n * eb;
+    HIP_TRY(anemoi::field_ops(field)->jive(2, 2, lvl, next, n, pc, s));
+    lvl = next;
+  }
+  return ANEMOI_OK;
+}
+
+int anemoi_merkle_climb_dev(int field, const void* d_leaves, const void* d_index, const void* d_paths, unsigned depth,
+                            size_t n, void* d_roots, void* stream) {
+  int rc = check_instance(field, 2);
+  if (rc) return rc;
+  if (depth > 63 || (n && (!d_leaves || !d_index || !d_roots || (depth && !d_paths)))) return ANEMOI_ERR_ARG;
+  PermConsts pc;
+  if ((rc = get_consts(field, 2, &pc))) return rc;
+  HIP_TRY(anemoi::field_ops(field)->merkle_climb(d_leaves, d_index, d_paths, depth, n, d_roots, pc, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
 int anemoi_to_montgomery_dev(int field, const void* d_in, void* d_out, size_t count, void* stream) {
   if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
   if (count && (!d_in || !d_out)) return ANEMOI_ERR_ARG;
@@ -424,6 +456,104 @@ int anemoi_from_montgomery(int field, const uint64_t* in, uint64_t* out, size_t 
   const size_t eb = elem_bytes(field);
   return host_batch(device, count, in, eb, out, eb, [&](void* i, void* o, size_t cnt) {
     return anemoi_from_montgomery_dev(field, i, o, cnt, nullptr);
+  });
+}
+
+int anemoi_merkle_tree(int field, const uint64_t* leaves, unsigned depth, uint64_t* tree, int device) {
+  int rc = check_instance(field, 2);
+  if (rc) return rc;
+  if (!leaves || !tree || depth > 30) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field), total = (size_t(2) << depth) - 1;
+  return for_devices(device == ANEMOI_ALL_DEVICES ? 0 : device, 1, [&](int dev, size_t, size_t) -> int {
+    DeviceGuard guard;
+    HIP_TRY(hipSetDevice(dev));
+    DevBuf dt;
+    int r = dt.alloc(total * eb);
+    if (r) return r;
+    HIP_TRY(hipMemcpy(dt.p, leaves, (size_t(1) << depth) * eb, hipMemcpyHostToDevice));
+    r = anemoi_merkle_tree_dev(field, dt.p, depth, dt.p, nullptr);
+    if (r) return r;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(tree, dt.p, total * eb, hipMemcpyDeviceToHost));
+    return ANEMOI_OK;
+  });
+}
+
+/* host-side indexing only: the sibling of node (level l, position index >> l) for l = 0 .. depth-1 */
+int anemoi_merkle_path(int field, const uint64_t* tree, unsigned depth, size_t index, uint64_t* path) {
+  if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
+  if (!tree || (depth && !path) || depth > 30 || index >= (size_t(1) << depth)) return ANEMOI_ERR_ARG;
+  const size_t L = anemoi::field_ops(field)->limbs64;
+  size_t off = 0;
+  for (unsigned l = 0; l < depth; l++) {
+    const size_t pos = (index >> l) ^ 1;
+    memcpy(path + l * L, tree + (off + pos) * L, L * 8);
+    off += size_t(1) << (depth - l);
+  }
+  return ANEMOI_OK;
+}
+
+int anemoi_merkle_verify_batch(int field, const uint64_t* leaves, const uint64_t* indices, const uint64_t* paths,
+                               unsigned depth, size_t n, const uint64_t* root, uint8_t* ok, int device) {
+  int rc = check_instance(field, 2);
+  if (rc) return rc;
+  if (depth > 63 || (n && (!leaves || !indices || !root || !ok || (depth && !paths)))) return ANEMOI_ERR_ARG;
+  if (n == 0) return ANEMOI_OK;
+  const size_t eb = elem_bytes(field);
+  return for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
+    if (!count) return ANEMOI_OK;
+    DeviceGuard guard;
+    HIP_TRY(hipSetDevice(dev));
+    DevBuf dl, di, dp, dr;
+    int r = dl.alloc(count * eb);
+    if (!r) r = di.alloc(count * 8);
+    if (!r) r = dp.alloc(count * depth * eb);
+    if (!r) r = dr.alloc(count * eb);
+    if (r) return r;
+    HIP_TRY(hipMemcpy(dl.p, (const char*)leaves + first * eb, count * eb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(di.p, indices + first, count * 8, hipMemcpyHostToDevice));
+    if (depth)
+      HIP_TRY(hipMemcpy(dp.p, (const char*)paths + first * depth * eb, count * depth * eb, hipMemcpyHostToDevice));
+    r = anemoi_merkle_climb_dev(field, dl.p, di.p, dp.p, depth, count, dr.p, nullptr);
+    if (r) return r;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint64_t> got(count * (eb / 8));
+    HIP_TRY(hipMemcpy(got.data(), dr.p, count * eb, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < count; i++) ok[first + i] = memcmp(&got[i * (eb / 8)], root, eb) == 0 ? 1 : 0;
+    return ANEMOI_OK;
+  });
+}
+
+/* Arity-4 tree with the 4-3 instance's Jive-4 (compress_k(.,4), anemoi_4_3/hasher.rs:162-179):
+ * 4^depth4 leaf digests -> root, level by level. */
+int anemoi_merkle_root_arity4(int field, const uint64_t* leaves, unsigned depth4, uint64_t* root, int device) {
+  int rc = check_instance(field, 4);
+  if (rc) return rc;
+  if (!leaves || !root || depth4 > 15) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field), nleaf = size_t(1) << (2 * depth4);
+  if (depth4 == 0) {
+    memcpy(root, leaves, eb);
+    return ANEMOI_OK;
+  }
+  return for_devices(device == ANEMOI_ALL_DEVICES ? 0 : device, 1, [&](int dev, size_t, size_t) -> int {
+    DeviceGuard guard;
+    HIP_TRY(hipSetDevice(dev));
+    DevBuf da, db;
+    int r = da.alloc(nleaf * eb);
+    if (!r) r = db.alloc(nleaf / 4 * eb);
+    if (r) return r;
+    HIP_TRY(hipMemcpy(da.p, leaves, nleaf * eb, hipMemcpyHostToDevice));
+    PermConsts pc;
+    if ((r = get_consts(field, 4, &pc))) return r;
+    void *src = da.p, *dst = db.p;
+    for (size_t n = nleaf / 4; n >= 1; n /= 4) {
+      HIP_TRY(anemoi::field_ops(field)->jive(4, 4, src, dst, n, pc, nullptr));
+      std::swap(src, dst);
+      if (n == 1) break;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(root, src, eb, hipMemcpyDeviceToHost));
+    return ANEMOI_OK;
   });
 }
 

@@ -109,6 +109,24 @@ int anemoi_hash_bytes_batch(int field, int width, const uint8_t *msgs, size_t ms
  * builds a contiguous subtree and the top log2(#GPUs) levels finish on the first device. */
 int anemoi_merkle_root(int field, const uint64_t *leaves, unsigned depth, uint64_t *root, int device);
 
+/* Merkle tree with every level retained (the realistic caller of merge):
+ * tree = level 0 (the 2^depth leaves) | level 1 | ... | level depth (the root), 2^(depth+1) - 1
+ * elements in all; node j of level l has children 2j, 2j+1 of level l-1. */
+int anemoi_merkle_tree(int field, const uint64_t *leaves, unsigned depth, uint64_t *tree, int device);
+
+/* Authentication path of leaf `index` out of a retained tree: `depth` sibling digests, bottom-up
+ * (host-side indexing, no device work). */
+int anemoi_merkle_path(int field, const uint64_t *tree, unsigned depth, size_t index, uint64_t *path);
+
+/* Batched path verification on the GPU: item i recomputes the root from leaves[i], indices[i] and its
+ * depth-element path (depth sequential merges per lane) and ok[i] = (it equals `root`). */
+int anemoi_merkle_verify_batch(int field, const uint64_t *leaves, const uint64_t *indices, const uint64_t *paths,
+                               unsigned depth, size_t n, const uint64_t *root, uint8_t *ok, int device);
+
+/* Arity-4 tree built with the 4-3 instance's Jive-4 compression (compress_k(.,4),
+ * anemoi_4_3/hasher.rs:162-179): 4^depth4 leaf digests -> root (depth4 <= 15). */
+int anemoi_merkle_root_arity4(int field, const uint64_t *leaves, unsigned depth4, uint64_t *root, int device);
+
 /* canonical little-endian integers (< p) <-> Montgomery elements.  from_montgomery's output is
  * exactly AnemoiDigest::to_bytes (src/<f>/anemoi_x/digest.rs:42-46) when viewed as bytes. */
 int anemoi_to_montgomery(int field, const uint64_t *in, uint64_t *out, size_t count, int device);
@@ -125,6 +143,11 @@ int anemoi_hash_bytes_dev(int field, int width, const void *d_msgs, size_t msg_l
 /* d_scratch: at least 2^depth elements; d_root: 1 element; d_leaves is not modified. */
 int anemoi_merkle_root_dev(int field, const void *d_leaves, unsigned depth, void *d_scratch, void *d_root,
                            void *stream);
+/* d_tree: 2^(depth+1) - 1 elements, laid out as anemoi_merkle_tree; may alias d_leaves at its start. */
+int anemoi_merkle_tree_dev(int field, const void *d_leaves, unsigned depth, void *d_tree, void *stream);
+/* d_index: n x uint64; d_paths: n x depth elements; d_roots: n recomputed roots. */
+int anemoi_merkle_climb_dev(int field, const void *d_leaves, const void *d_index, const void *d_paths,
+                            unsigned depth, size_t n, void *d_roots, void *stream);
 int anemoi_to_montgomery_dev(int field, const void *d_in, void *d_out, size_t count, void *stream);
 int anemoi_from_montgomery_dev(int field, const void *d_in, void *d_out, size_t count, void *stream);
 

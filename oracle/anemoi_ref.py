@@ -171,3 +171,29 @@ class Instance:
         while len(level) > 1:
             level = [self.merge(level[2 * i], level[2 * i + 1]) for i in range(len(level) // 2)]
         return level[0]
+
+    def merkle_levels(self, leaves):
+        levels = [list(leaves)]
+        while len(levels[-1]) > 1:
+            cur = levels[-1]
+            levels.append([self.merge(cur[2 * i], cur[2 * i + 1]) for i in range(len(cur) // 2)])
+        return levels
+
+    @staticmethod
+    def merkle_path(levels, index):
+        """siblings of leaf `index`, bottom-up"""
+        return [levels[l][(index >> l) ^ 1] for l in range(len(levels) - 1)]
+
+    def merkle_climb(self, leaf, index, path):
+        cur = leaf
+        for l, sib in enumerate(path):
+            cur = self.merge(sib, cur) if (index >> l) & 1 else self.merge(cur, sib)
+        return cur
+
+    def merkle_root_arity4(self, leaves):
+        """4-3 instance, Jive-4: parent = compress_k([c0, c1, c2, c3], 4)[0]"""
+        assert self.width == 4
+        level = list(leaves)
+        while len(level) > 1:
+            level = [self.compress_k(level[4 * i: 4 * i + 4], 4)[0] for i in range(len(level) // 4)]
+        return level[0]

@@ -167,6 +167,50 @@ def test_merkle_vs_oracle(A, oracle, params, field):
     assert (A.Anemoi(field, 2, device=A.ALL_DEVICES).merkle_root(leaves, 7) == inst.merkle_root(leaves, 7)).all()
 
 
+@pytest.mark.parametrize("field", ["jubjub", "bls12_381", "ed_on_bls12_377"])
+def test_merkle_tree_paths_verify(A, oracle, params, field):
+    """Retained-level tree, authentication paths and batched verification vs the Python restatement."""
+    from anemoi_ref import Instance
+    I, fid = Instance(field, 2), FIELD_IDS.index(field)
+    inst, depth = A.Anemoi(field, 2), 5
+    rng = random.Random(31 + fid)
+    leaves_i = [rng.randrange(I.p) for _ in range(1 << depth)]
+    levels_i = I.merkle_levels(leaves_i)
+    leaves = oracle.ints_to_mont(fid, leaves_i)
+    levels = inst.merkle_tree(leaves, depth)
+    assert [len(l) for l in levels] == [32, 16, 8, 4, 2, 1]
+    for got, exp in zip(levels, levels_i):
+        assert inst.decode(got) == exp
+    idx = [0, 1, 13, 31, 18]
+    paths = np.stack([inst.merkle_path(levels, depth, i) for i in idx])
+    for i, pth in zip(idx, paths):
+        assert inst.decode(pth) == I.merkle_path(levels_i, i)
+        assert I.merkle_climb(leaves_i[i], i, I.merkle_path(levels_i, i)) == levels_i[-1][0]
+    ok = inst.merkle_verify_batch(leaves[idx], idx, paths, depth, levels[-1][0])
+    assert ok.all()
+    # tampering: wrong index, wrong leaf, wrong sibling must all be rejected
+    bad_idx = inst.merkle_verify_batch(leaves[idx], [1, 0, 12, 30, 19], paths, depth, levels[-1][0])
+    assert not bad_idx.any()
+    bad_paths = paths.copy()
+    bad_paths[:, 2, 0] ^= np.uint64(1)
+    assert not inst.merkle_verify_batch(leaves[idx], idx, bad_paths, depth, levels[-1][0]).any()
+    assert not inst.merkle_verify_batch(leaves[[1, 0, 14, 30, 17]], idx, paths, depth, levels[-1][0]).any()
+    # depth 0: the leaf is the root
+    assert inst.merkle_verify_batch(leaves[:1], [0], np.zeros((1, 0, inst.limbs), np.uint64), 0, leaves[0]).all()
+
+
+@pytest.mark.parametrize("field", ["bn_254", "bls12_377"])
+def test_merkle_arity4(A, oracle, params, field):
+    from anemoi_ref import Instance
+    I, fid = Instance(field, 4), FIELD_IDS.index(field)
+    inst = A.Anemoi(field, 4)
+    rng = random.Random(77 + fid)
+    for depth4 in (0, 1, 3):
+        leaves_i = [rng.randrange(I.p) for _ in range(4 ** depth4)]
+        got = inst.merkle_root_arity4(oracle.ints_to_mont(fid, leaves_i), depth4)
+        assert inst.decode(got) == [I.merkle_root_arity4(leaves_i)]
+
+
 def test_golden_extra_vectors(A, oracle):
     """Vectors minted by tools/mint_goldens.py from the Python big-int restatement for the cases the
     reference's tests leave unpinned (partial chunk, empty input, 10 KB messages, Merkle roots)."""
