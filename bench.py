@@ -103,12 +103,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    # one process per GPU; ANEMOI_BENCH_BACKEND=gloo lets the N > 1 path be rehearsed on a box with
+    # fewer GPUs than ranks (ranks then share devices round-robin; timing is meaningless there)
+    backend = os.environ.get("ANEMOI_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1) if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import anemoi_amd as A  # after torch: binds to the same HIP runtime
     from anemoi_amd.shard import max_over_ranks
@@ -143,7 +151,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-    elapsed = max_over_ranks(elapsed, dist, dev)
+    elapsed = max_over_ranks(elapsed, dist, dev if backend == "nccl" else None)
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
 
     # spot-check the timed output against the C-ABI's own single-item path is the tests' job; here only
