@@ -12,9 +12,11 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "anemoi_perm.h"
+#include "coop29.h"
 
 namespace anemoi {
 
@@ -294,6 +296,85 @@ ANEMOI_KERNEL void k_merkle_climb(const uint4* __restrict__ leaves, const uint64
   block_store<Q>(lds, out, blk0, cnt);
 }
 
+// ---- wave-cooperative Jive 2-to-1 compression (one item per wavefront, coop29.h) -----------------------
+// Latency path: used for small batches (coop_max_items(): the top levels of a Merkle tree, a
+// single Jive::compress / Sponge::merge call).  Same round function and the same bound bookkeeping as
+// the lane-private kernels; the window table (5-bit window: 16 odd powers, one word per lane each)
+// sits in LDS.
+// Batches up to this many items take the cooperative kernel: measured on Merkle trees
+// (profiles/r01/merkle_cooperative_threshold_sweep.txt) the best cut is ~2048 items for the 14-limb
+// fields (depth-18 BLS12-381 tree 164.7 -> 120.9 ms) and ~1024 for the 9-limb ones (depth-21 Jubjub
+// tree 139.2 -> 132.8 ms).  ANEMOI_COOP_MAX overrides it (0 = always lane-private, a huge value =
+// always cooperative); the parity tests run both ways.
+inline size_t coop_max_items(int limbs29) {
+  static const long long env = [] {
+    const char* e = getenv("ANEMOI_COOP_MAX");
+    return e ? (long long)strtoull(e, nullptr, 10) : -1ll;
+  }();
+  if (env >= 0) return size_t(env);
+  return limbs29 >= 14 ? 2048 : 1024;
+}
+
+template <int FIELD>
+__global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                       size_t n, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using C = Coop29<F>;
+  constexpr int NL = C::NL, NABI = C::NABI, R = F::kRounds21, E = 16;
+  __shared__ uint32_t tab[E * kBlock];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t pl = C::konst(F::P29), kpl = C::konst(F::KP29), delta = C::konst(F::Delta29);
+  for (size_t item = blockIdx.x; item < n; item += gridDim.x) {
+    const uint32_t w0 = lane < NABI ? in[(item * 2 + 0) * NABI + lane] : 0u;
+    const uint32_t w1 = lane < NABI ? in[(item * 2 + 1) * NABI + lane] : 0u;
+    const uint32_t e0 = C::from_abi(w0, pl), e1 = C::from_abi(w1, pl);
+    uint32_t x = e0, y = e1;
+#pragma nounroll
+    for (int r = 0; r <= R; r++) {
+      if (r < R) {  // ark_layer (src/traits.rs:111-125)
+        x = C::add(x, lane < NL ? pc.ark_c[r * NL + lane] : 0u);
+        y = C::add(y, lane < NL ? pc.ark_d[r * NL + lane] : 0u);
+      }
+      // mds_layer, NUM_COLUMNS = 1 (src/traits.rs:136-142), then back below 2p
+      y = C::add(y, x);
+      x = C::add(x, y);
+      x = C::settle(x, pl);
+      y = C::settle(y, pl);
+      if (r == R) break;  // permutation = R rounds + a final mds_layer (src/traits.rs:370-378)
+      // sbox_layer (src/traits.rs:326-358)
+      uint32_t t = C::mul(y, y, pl);
+      x = C::sub(x, C::mul_g(t, pl), kpl);
+      // x^(1/alpha): 5-bit sliding window, table of odd powers in LDS
+      {
+        const uint32_t x2 = C::mul(x, x, pl);
+        uint32_t pw = x;
+        tab[lane] = pw;
+#pragma nounroll
+        for (int i = 1; i < E; i++) {
+          pw = C::mul(pw, x2, pl);
+          tab[i * kBlock + lane] = pw;
+        }
+        uint32_t acc = tab[pc.first5 * kBlock + lane];
+#pragma nounroll
+        for (int s = 0; s < pc.steps5; s++) {
+          const int nsq = pc.sched5[2 * s], idx = pc.sched5[2 * s + 1];
+#pragma nounroll
+          for (int q = 0; q < nsq; q++) acc = C::mul(acc, acc, pl);
+          if (idx != 255) acc = C::mul(acc, tab[idx * kBlock + lane], pl);
+        }
+        t = acc;
+      }
+      y = C::sub(y, t, kpl);
+      t = C::mul(y, y, pl);
+      x = C::add(C::add(x, C::mul_g(t, pl)), delta);
+    }
+    // Jive feed-forward: state[0] + state[1] + elems[0] + elems[1] (anemoi_2_1/hasher.rs:102)
+    const uint32_t s = C::add(C::add(x, y), C::add(e0, e1));
+    const uint32_t o = C::to_abi(s, pl);
+    if (lane < NABI) out[item * NABI + lane] = o;
+  }
+}
+
 // to = true: canonical -> Montgomery (x * R^2 / R); to = false: Montgomery -> canonical (x * 1 / R).
 // Always on 32-bit limbs: this is the ABI's own R = 2^(32 N).
 template <int FIELD>
@@ -320,8 +401,8 @@ __global__ __launch_bounds__(kBlock) void k_mont_convert(const uint4* __restrict
 
 struct HostConsts {  // what the context uploads for one (field, width)
   std::vector<uint32_t> ark_c, ark_d;
-  std::vector<uint8_t> sched;
-  int steps, first;
+  std::vector<uint8_t> sched, sched5;
+  int steps, first, steps5, first5;
 };
 
 struct FieldOps {
@@ -354,6 +435,8 @@ struct Launch {
     hc->ark_c.assign(c, c + cnt);
     hc->ark_d.assign(d, d + cnt);
     static_assert(WIN >= 2 && WIN <= 5, "schedules are generated for 2..5-bit windows");
+    hc->sched5.assign(F::kW5Sched, F::kW5Sched + 2 * F::kW5Steps);
+    hc->steps5 = F::kW5Steps, hc->first5 = F::kW5First;
     if (WIN == 2) {
       hc->sched.assign(F::kW2Sched, F::kW2Sched + 2 * F::kW2Steps);
       hc->steps = F::kW2Steps, hc->first = F::kW2First;
@@ -384,6 +467,11 @@ struct Launch {
 
   static hipError_t jive(int width, int k, const void* in, void* out, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
+    if (width == 2 && n <= coop_max_items(F::NL29)) {  // latency path: one item per wavefront
+      const unsigned g = n < 65536 ? unsigned(n) : 65536u;  // the kernel strides over items
+      k_jive2_coop<FIELD><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
+      return hipGetLastError();
+    }
     if (width == 2)
       k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     else if (k == 2)

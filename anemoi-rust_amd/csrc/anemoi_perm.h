@@ -73,6 +73,10 @@ struct PermConsts {
   const uint8_t* sched;
   int steps;
   int first;
+  // 5-bit-window schedule for the wave-cooperative kernels (their table costs one VGPR/LDS word per entry)
+  const uint8_t* sched5;
+  int steps5;
+  int first5;
 };
 
 // r = x^INV_ALPHA.  WIN-bit sliding window over odd powers; table entry 0 is x itself (registers).

@@ -1,0 +1,141 @@
+// coop29.h -- wave-cooperative Montgomery arithmetic: ONE field element per wavefront, one 29-bit
+// limb per lane.  This is the low-latency path (small batches, the top levels of a Merkle tree, a
+// single `Jive::compress` through the shim); the lane-private path of mont29.h is the throughput
+// path (4x the multiplications per instruction, but one lane needs ~2.6 ms / 8.6 ms for a
+// 255-bit / 381-bit compression).
+//
+// Layout: lane j < NL holds limb j (same radix-2^29, R' = 2^(29 NL) Montgomery form as mont29.h);
+// lanes >= NL hold zero.  A Montgomery product is a systolic operand scan over the lanes:
+//     for i in 0..NL-1:
+//         t_j += a_i * b_j                     a_i broadcast with v_readlane (SGPR operand)
+//         m    = -(t_0) / p  mod 2^29          lane 0's low word -> SGPR, the multiply runs on the SALU
+//         t_j += m * p_j                       now t_0 = 0 mod 2^29
+//         t_j  = t_{j+1} (+ t_0 >> 29 in lane 0)   one DPP row_shl per accumulator word
+// followed by two DPP carry passes that leave limbs < 2^29 + 2^7 (good enough as multiplier input:
+// the column bound of mont29.h has a full bit of slack).  Where exact limbs are needed (before a
+// subtraction, before the final comparison with p) the remaining single-bit carries are resolved
+// with two wavefront ballots and one 64-bit scalar add -- carry look-ahead on the lane masks:
+//     G = ballot(limb >= 2^29), P = ballot(limb == 2^29 - 1), carry-in mask C = ((G << 1) + P) ^ P
+// and `v_addc_co_u32` consumes C directly as its per-lane carry-in.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "field_consts_gen.h"
+
+namespace anemoi {
+
+template <class F>
+struct Coop29 {
+  static constexpr int NL = F::NL29;
+  static constexpr int NABI = F::N;
+  static constexpr uint32_t MASK = (1u << 29) - 1;
+  static constexpr bool kTight = F::kH29 < 4096.0;
+
+  // DPP within row 0 (NL <= 14 < 16 lanes): out-of-range sources read as 0 (bound_ctrl)
+  __device__ static __forceinline__ uint32_t from_next(uint32_t v) {  // lane j <- lane j+1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+  }
+  __device__ static __forceinline__ uint32_t from_prev(uint32_t v) {  // lane j <- lane j-1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+  }
+  __device__ static __forceinline__ uint32_t lane() { return threadIdx.x; }
+  __device__ static __forceinline__ uint32_t keep(uint32_t v) { return lane() < NL ? v : 0u; }
+
+  // per-lane copy of a field constant (limb `lane`, 0 beyond NL)
+  __device__ static __forceinline__ uint32_t konst(const uint32_t* __restrict__ k) {
+    return lane() < NL ? k[lane()] : 0u;
+  }
+
+  // two carry passes: 64-bit column sums -> limbs < 2^29 + 2^7
+  __device__ static __forceinline__ uint32_t settle_columns(uint64_t t) {
+    const uint32_t lo = (uint32_t)t & MASK;
+    const uint64_t hi = t >> 29;  // < 2^35
+    const uint64_t up = ((uint64_t)from_prev((uint32_t)(hi >> 32)) << 32) | from_prev((uint32_t)hi);
+    const uint64_t r = (uint64_t)lo + up;  // < 2^36
+    const uint32_t lo2 = (uint32_t)r & MASK;
+    const uint32_t c = (uint32_t)(r >> 29);  // < 2^7
+    return keep(lo2 + from_prev(c));
+  }
+
+  // one carry pass for sums of a few almost-normalised limbs (values < 2^32)
+  __device__ static __forceinline__ uint32_t carry32(uint32_t r) {
+    return keep((r & MASK) + from_prev(r >> 29));
+  }
+
+  // limbs < 2^30 -> limbs < 2^29 exactly (ballot carry look-ahead, see the header comment)
+  __device__ static __forceinline__ uint32_t norm_exact(uint32_t r) {
+    r = carry32(r);  // now < 2^29 + 8: at most a single carry bit out of any limb
+    const unsigned long long G = __ballot(r > MASK), P = __ballot(r == MASK);
+    const unsigned long long C = ((G << 1) + P) ^ P;
+    return (r + (uint32_t)((C >> lane()) & 1)) & MASK;
+  }
+
+  // Montgomery product (limbs of a, b < 2^29 + 2^7): result < 2p when (a/p)(b/p) <= R'/p
+  __device__ static __forceinline__ uint32_t mul(uint32_t a, uint32_t b, uint32_t pl) {
+    uint64_t t = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const uint32_t ai = __builtin_amdgcn_readlane(a, i);
+      t += (uint64_t)ai * b;
+      const uint32_t t0 = __builtin_amdgcn_readlane((uint32_t)t, 0);
+      const uint32_t m = (t0 * F::kN0Inv29) & MASK;
+      t += (uint64_t)m * pl;
+      const uint64_t u = lane() == 0 ? (t >> 29) : 0ull;
+      t = (((uint64_t)from_next((uint32_t)(t >> 32)) << 32) | from_next((uint32_t)t)) + u;
+    }
+    return settle_columns(t);
+  }
+
+  __device__ static __forceinline__ uint32_t add(uint32_t a, uint32_t b) { return carry32(a + b); }
+
+  // a - b + kSubK29 * p (b < ~60 p, or < 2p for the tight fields); KP29 limbs are padded to >= 2^29 - 1
+  __device__ static __forceinline__ uint32_t sub(uint32_t a, uint32_t b, uint32_t kpl) {
+    return carry32(a + kpl - norm_exact(b));
+  }
+
+  // g * x (mul_by_generator, src/traits.rs:78-91)
+  __device__ static __forceinline__ uint32_t mul_g(uint32_t x, uint32_t pl) {
+    if constexpr (kTight) return mul(x, konst(F::GMont29), pl);
+    return settle_columns((uint64_t)x * (uint32_t)F::kG);
+  }
+
+  __device__ static __forceinline__ uint32_t settle(uint32_t x, uint32_t pl) { return mul(x, konst(F::One29), pl); }
+
+  // x < 2p -> x mod p, exact limbs
+  __device__ static __forceinline__ uint32_t canonical(uint32_t x, uint32_t pl) {
+    x = norm_exact(x);
+    // borrow look-ahead for x - p: generate where x_j < p_j, propagate where equal
+    const unsigned long long G = __ballot(x < pl), P = __ballot(x == pl && lane() < NL);
+    const unsigned long long B = ((G << 1) + P) ^ P;           // borrow-in per limb
+    const bool below = (((G << 1) + P) >> NL) & 1;              // borrow out of the top limb: x < p
+    const uint32_t d = (x - pl - (uint32_t)((B >> lane()) & 1)) & MASK;
+    return below ? x : keep(d);
+  }
+
+  // ABI words (lane j < NABI holds 32-bit word j of x * 2^(32 NABI) mod p) -> internal limbs
+  __device__ static __forceinline__ uint32_t words_to_limbs(uint32_t w) {
+    const int bit = 29 * (int)lane(), lo = bit >> 5, sh = bit & 31;
+    const uint32_t wl = __shfl(w, lo < NABI ? lo : 0), wh = __shfl(w, lo + 1 < NABI ? lo + 1 : 0);
+    const uint32_t a = lo < NABI ? wl : 0u, b = lo + 1 < NABI ? wh : 0u;
+    const uint32_t v = sh == 0 ? a : ((a >> sh) | (b << (32 - sh)));
+    return keep(v & MASK);
+  }
+  __device__ static __forceinline__ uint32_t limbs_to_words(uint32_t l) {  // exact limbs, value < 2^(32 NABI)
+    const int bit = 32 * (int)lane(), i0 = bit / 29, off = bit - 29 * i0;
+    const uint32_t l0 = __shfl(l, i0 < 64 ? i0 : 0), l1 = __shfl(l, i0 + 1 < 64 ? i0 + 1 : 0),
+                   l2 = __shfl(l, i0 + 2 < 64 ? i0 + 2 : 0);
+    uint32_t v = l0 >> off;
+    v |= off == 0 ? (l1 << 29) : (l1 << (29 - off));
+    if (58 - off < 32) v |= l2 << (58 - off);
+    return lane() < NABI ? v : 0u;
+  }
+  __device__ static __forceinline__ uint32_t from_abi(uint32_t w, uint32_t pl) {
+    return mul(words_to_limbs(w), konst(F::In29), pl);
+  }
+  __device__ static __forceinline__ uint32_t to_abi(uint32_t x, uint32_t pl) {
+    return limbs_to_words(canonical(mul(x, konst(F::Out29), pl), pl));
+  }
+};
+
+}  // namespace anemoi

@@ -280,3 +280,37 @@ def test_cfg5_jubjub_merkle_depth14(A, oracle, params):
     l, r = inst.merkle_root(leaves[: 1 << 13], 13), inst.merkle_root(leaves[1 << 13:], 13)
     assert (inst.merge(np.stack([l, r])) == root).all()
     assert (root == oracle.merkle_root(fid, leaves, 14)).all()
+
+
+def test_cooperative_and_lane_private_paths_agree(oracle, params):
+    """Jive 2-1 has two kernels: wave-cooperative (one item per wavefront, batches <= 2048) and
+    lane-private (one item per lane).  ANEMOI_COOP_MAX forces each for every size; both must match the
+    oracle bit for bit on all 7 fields, ragged sizes and edge states."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    code = r'''
+import sys, os, random
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "anemoi-rust_amd"))
+import orc, anemoi_amd as A
+oracle = orc.Oracle()
+import json
+params = json.load(open(os.path.join(ROOT, "tests", "golden", "params.json")))
+for fid, field in enumerate(A.FIELD_IDS):
+    p, L = int(params[field]["modulus"]), params[field]["u64_limbs"]
+    rng = random.Random(fid)
+    for n in (1, 2, 65, 300):
+        st = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(2 * n)]).reshape(n, 2, L)
+        st[0] = 0
+        if n > 1:
+            st[1] = oracle.ints_to_mont(fid, [p - 1, p - 1])
+        got = A.Anemoi(field, 2).compress_batch(st)
+        assert (got == oracle.compress_batch(fid, 2, st, threads=8)).all(), (field, n)
+    leaves = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(64)])
+    assert (A.Anemoi(field, 2).merkle_root(leaves, 6) == oracle.merkle_root(fid, leaves, 6)).all()
+print("ok")
+'''.replace("ROOT", repr(ROOT))
+    for coop_max in ("0", "1000000000"):
+        env = dict(os.environ, ANEMOI_COOP_MAX=coop_max)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "ok" in out.stdout, (coop_max, out.stdout[-1500:], out.stderr[-1500:])
