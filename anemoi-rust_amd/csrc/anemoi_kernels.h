@@ -22,8 +22,9 @@ namespace anemoi {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: the LDS window table is lane-private
 
-// Register budget: ANEMOI_WAVES waves per SIMD (0 = let the compiler choose).  The multiplier is
-// issue-latency bound, so occupancy is worth more than registers (tools/ubench/valu_rates.hip).
+// Register budget: ANEMOI_WAVES waves per SIMD (0 = let the compiler choose; the shipped setting).
+// Forcing 5-8 waves/SIMD was measured and is slower: the kernels are VALU-issue bound at 3 waves
+// (profiles/r01/ab_occupancy_variants.txt).
 #ifndef ANEMOI_WAVES
 #define ANEMOI_WAVES 0
 #endif
@@ -43,8 +44,7 @@ struct KernelCfg {
 
 template <class A, int WIN>
 constexpr size_t lds_table_bytes() {
-  // x^3, x^5, ..: x itself stays in VGPRs (ANEMOI_PARK: x and y are parked in two more slots)
-  return size_t((1 << (WIN - 1)) - 1 + (ANEMOI_PARK ? 2 : 0)) * A::NQ * 16 * kBlock;
+  return size_t((1 << (WIN - 1)) - 1) * A::NQ * 16 * kBlock;  // x^3, x^5, ..: x itself stays in VGPRs
 }
 
 template <class A, int WIN, int W>

@@ -18,10 +18,6 @@
 #pragma once
 #include <type_traits>
 
-#ifndef ANEMOI_PARK
-#define ANEMOI_PARK 0
-#endif
-
 #include "field_consts_gen.h"
 #include "mont29.h"
 #include "mont32.h"
@@ -86,38 +82,23 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
                                               const LdsTable<A>& tab) {
   constexpr int E = 1 << (WIN - 1);
   typename A::Fe x2, t, acc;
-#if ANEMOI_PARK
-  // park x as table entry 0 (slot E) so nothing but the accumulator is live in the hot loop
-  tab.store(E, x);
-  A::esqr(x2, x);
-  tab.load(E, t);
-#else
   A::esqr(x2, x);
   t = x;
-#endif
 #pragma nounroll
   for (int i = 1; i < E; i++) {
     A::emul(t, t, x2);
     tab.store(i, t);
   }
-#if ANEMOI_PARK
-  tab.load(pc.first == 0 ? E : pc.first, acc);
-#else
   if (pc.first == 0) acc = x;
   else tab.load(pc.first, acc);
-#endif
 #pragma nounroll
   for (int s = 0; s < pc.steps; s++) {
     const int nsq = pc.sched[2 * s], idx = pc.sched[2 * s + 1];
 #pragma nounroll
     for (int q = 0; q < nsq; q++) A::esqr(acc, acc);
     if (idx != 255) {
-#if ANEMOI_PARK
-      tab.load(idx == 0 ? E : idx, t);
-#else
       if (idx == 0) t = x;
       else tab.load(idx, t);
-#endif
       A::emul(acc, acc, t);
     }
   }
@@ -140,15 +121,7 @@ __device__ __forceinline__ void flystel(typename A::Fe& x, typename A::Fe& y, co
   A::sqr(t, y);
   A::mul_g(u, t);
   A::sub(x, x, u);
-#if ANEMOI_PARK
-  constexpr int E = 1 << (WIN - 1);
-  tab.store(E + 1, y);
   exp_inv_alpha<F, A, WIN>(t, x, pc, tab);
-  tab.load(E, x);
-  tab.load(E + 1, y);
-#else
-  exp_inv_alpha<F, A, WIN>(t, x, pc, tab);
-#endif
   A::sub(y, y, t);
   A::sqr(t, y);
   A::mul_g(u, t);

@@ -49,26 +49,17 @@ struct Arith29 {
   //   X_k = sum_j a_j b_{k-j}            (no dependence on the reduction digits m)
   //   M_k = sum_{j<k} m_j p_{k-j}        (only its last term m_{k-1} p_1 waits for the previous column)
   //   m_k = -(low 29 bits) / p mod 2^29
-  // ANEMOI_ILP >= 1 keeps X_k (and with 2 also the early terms of M_k) in accumulators of their own,
-  // so the serial v_mad_u64_u32 chain through `acc` is only ~5 instructions per column and the
-  // scheduler can overlap the rest (the multiplier is issue-latency bound, not throughput bound).
-#ifndef ANEMOI_ILP
-#define ANEMOI_ILP 2
-#endif
-#ifndef ANEMOI_NO_A2
-#define ANEMOI_NO_A2 0
-#endif
+  // hipcc reassociates these sums into an operand-scanning schedule with ~20 live column
+  // accumulators (150 VGPRs, 3 waves/SIMD): 301 v_mad_u64_u32 + 111 other instructions per squaring.
+  // Forcing a leaner schedule (fewer registers, 5-8 waves/SIMD) was measured and is slower: the
+  // multiplier is bound by VALU issue, not by occupancy (profiles/r01/ab_occupancy_variants.txt).
   __device__ static __forceinline__ void mul(Fe& r, const Fe& a, const Fe& b) {
     uint32_t m[NL], out[NL];
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
       const int j0 = k < NL ? 0 : k - NL + 1, j1 = k < NL ? k : NL - 1;
-#if ANEMOI_ILP < 0
-      uint64_t& x = acc;  // single accumulator: products go straight into the column sum
-#else
       uint64_t x = 0;
-#endif
 #pragma unroll
       for (int j = j0; j <= j1; j++) x += (uint64_t)a.l[j] * b.l[k - j];
       column_tail(acc, x, m, out, k);
@@ -81,30 +72,16 @@ struct Arith29 {
   // Montgomery square.  Off-diagonal products use a pre-doubled copy of a (limb-wise doubling is
   // exact with unsaturated limbs: 2*l[i] < 2^30), so each costs one multiply-accumulate.
   __device__ static __forceinline__ void sqr(Fe& r, const Fe& a) {
-    uint32_t m[NL], out[NL];
-#if !ANEMOI_NO_A2
-    uint32_t a2[NL];
+    uint32_t m[NL], out[NL], a2[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
-#endif
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
       const int j0 = k < NL ? 0 : k - NL + 1;
-#if ANEMOI_ILP < 0 && !ANEMOI_NO_A2
-      uint64_t& x = acc;
-#else
       uint64_t x = 0;
-#endif
-#if ANEMOI_NO_A2
-      // register-lean form: sum the off-diagonal products once, double the sum (one v_lshl_add_u64)
-#pragma unroll
-      for (int j = j0; j < k - j; j++) x += (uint64_t)a.l[j] * a.l[k - j];
-      x <<= 1;
-#else
 #pragma unroll
       for (int j = j0; j < k - j; j++) x += (uint64_t)a2[j] * a.l[k - j];
-#endif
       if ((k & 1) == 0) x += (uint64_t)a.l[k / 2] * a.l[k / 2];
       column_tail(acc, x, m, out, k);
     }
@@ -117,19 +94,11 @@ struct Arith29 {
   __device__ static __forceinline__ void column_tail(uint64_t& acc, uint64_t x, uint32_t (&m)[NL], uint32_t (&out)[NL],
                                                      const int k) {
     const int j0 = k < NL ? 0 : k - NL + 1, j1 = k < NL ? k - 1 : NL - 1;  // m_j p_{k-j}, j in [j0, j1]
-#if ANEMOI_ILP >= 2
     uint64_t early = x;
 #pragma unroll
     for (int j = j0; j < j1; j++) early += (uint64_t)m[j] * F::P29[k - j];
     acc += early;
     if (j1 >= j0) acc += (uint64_t)m[j1] * F::P29[k - j1];
-#else
-#if ANEMOI_ILP >= 0 || ANEMOI_NO_A2
-    acc += x;
-#endif
-#pragma unroll
-    for (int j = j0; j <= j1; j++) acc += (uint64_t)m[j] * F::P29[k - j];
-#endif
     if (k < NL) {
       m[k] = ((uint32_t)acc * F::kN0Inv29) & MASK;
       acc += (uint64_t)m[k] * F::P29[0];
