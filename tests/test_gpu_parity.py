@@ -270,6 +270,46 @@ def test_cfg3_bn254_sponge_10k(A, oracle):
     assert (got == exp[idx]).all()
 
 
+def test_cfg3_full_size_2pow16_messages(A, oracle):
+    """BASELINE config 3 at its full size: 2^16 messages x 10 240 bytes (640 MiB).  Messages are drawn
+    from 16 distinct ones, so every digest is known from the oracle: checks all 65 536 lanes."""
+    fid = FIELD_IDS.index("bn_254")
+    rng = np.random.default_rng(0xA9E30133)
+    base = rng.integers(0, 256, size=(16, 10240), dtype=np.uint8)
+    idx = rng.integers(0, 16, size=1 << 16)
+    got = A.Anemoi("bn_254", 4).hash_batch(base[idx])
+    exp = oracle.hash_bytes_batch(fid, 4, base, threads=8)
+    assert (got == exp[idx]).all()
+
+
+def test_cfg4_per_gpu_share_2pow21(A, oracle, params):
+    """BASELINE config 4's per-GPU share (2^24 / 8 = 2^21 BLS12-381 compressions): equal inputs give
+    equal outputs across the whole batch, the distinct ones match the oracle."""
+    fid, p = 0, int(params["bls12_381"]["modulus"])
+    rng = np.random.default_rng(0xA9E30104)
+    base = rand_elems(oracle, fid, p, 2 * 256, 0xA9E30104).reshape(256, 2, 6)
+    idx = rng.integers(0, 256, size=1 << 21)
+    out = A.Anemoi("bls12_381", 2).compress_batch(base[idx])
+    exp = oracle.compress_batch(fid, 2, base, threads=8)
+    assert (out == exp[idx]).all()
+
+
+def test_cfg5_per_gpu_subtree_depth21(A, oracle, params):
+    """BASELINE config 5's per-GPU subtree (2^21 Jubjub leaves): root == merge(root(left half),
+    root(right half)) (a size-independent property; depth 14 below is checked against the oracle) and
+    the retained-level tree agrees with the root driver."""
+    fid, p = FIELD_IDS.index("jubjub"), int(params["jubjub"]["modulus"])
+    inst = A.Anemoi("jubjub", 2)
+    rng = np.random.default_rng(0xA9E30155)
+    leaves = rng.integers(0, 1 << 62, size=(1 << 21, 4), dtype=np.uint64)   # limbs < 2^62 => element < p
+    root = inst.merkle_root(leaves, 21)
+    l, r = inst.merkle_root(leaves[: 1 << 20], 20), inst.merkle_root(leaves[1 << 20:], 20)
+    assert (inst.merge(np.stack([l, r])) == root).all()
+    levels = inst.merkle_tree(leaves[: 1 << 16], 16)
+    assert (levels[-1][0] == inst.merkle_root(leaves[: 1 << 16], 16)).all()
+    assert (levels[1][:64] == oracle.compress_batch(fid, 2, leaves[:128].reshape(64, 2, 4), threads=8)[:, 0]).all()
+
+
 def test_cfg5_jubjub_merkle_depth14(A, oracle, params):
     """BASELINE config 5 shape at depth 14 (2^14 leaves): root == merge of the two half-tree roots
     (recursively, a size-independent property) and == the oracle's root."""
