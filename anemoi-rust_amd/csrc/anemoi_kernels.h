@@ -1,9 +1,13 @@
-// anemoi_kernels.h -- batch kernels (one item per lane) and their launchers, templated on the field.
+// anemoi_kernels.h -- batch kernels and their launchers, templated on the field.
 //
-//   k_permutation   Anemoi::permutation            src/traits.rs:370-378
-//   k_jive          Jive::compress / compress_k    src/<f>/anemoi_2_1/hasher.rs:96-110, anemoi_4_3/hasher.rs:148-179
-//   k_sponge        Sponge::hash / hash_field      src/<f>/anemoi_2_1/hasher.rs:18-85, anemoi_4_3/hasher.rs:19-129
-//   k_mont_convert  canonical <-> Montgomery (arkworks into_bigint / from_bigint)
+// one item per lane (throughput path):
+//   k_permutation   Anemoi::permutation / sbox_layer   src/traits.rs:370-378, :326-358
+//   k_jive          Jive::compress / compress_k        src/<f>/anemoi_2_1/hasher.rs:96-110, anemoi_4_3/hasher.rs:148-179
+//   k_sponge        Sponge::hash / hash_field          src/<f>/anemoi_2_1/hasher.rs:18-85, anemoi_4_3/hasher.rs:19-129
+//   k_merkle_climb  authentication-path verification   (depth x Sponge::merge, anemoi_2_1/hasher.rs:87-92)
+//   k_mont_convert  canonical <-> Montgomery           (arkworks into_bigint / from_bigint)
+// one item per wavefront (latency path, small batches):
+//   k_jive2_coop    Jive::compress 2-1 / Sponge::merge on the wave-cooperative arithmetic of coop29.h
 //
 // Data layout in HBM: array-of-states, each state `W` elements of N 32-bit limbs (= the reference's
 // `&[Felt]` bytes).  A workgroup's states are contiguous, so it moves them with 16-byte-per-lane
@@ -35,7 +39,7 @@ constexpr int kBlock = 64;  // one wavefront per workgroup: the LDS window table
 #endif
 
 #ifndef ANEMOI_WIN
-#define ANEMOI_WIN 4
+#define ANEMOI_WIN 3  // 3 LDS entries per lane -> 13 waves per CU; see DESIGN.md section 3.3
 #endif
 template <int N>
 struct KernelCfg {
