@@ -152,6 +152,20 @@ ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out,
   typename A::Fe st[W], sum[C];
   static_for<0, W>([&](auto i) { lds_get<A>(lds, threadIdx.x * W + i, st[i]); });
   __syncthreads();
+  // Jive feed-forward sum of the inputs.  9-limb fields, W = 2: kept in 9 VGPRs across the
+  // permutation (+9.6 % on Jubjub against re-reading, A/B in one process).  Otherwise the inputs are
+  // fetched again at the end (from L2 / Infinity Cache: measured HBM traffic 1.4x the algorithmic
+  // bytes): holding 14 VGPRs costs the BLS12-381 2-1 kernel 1.2 %, and the W = 4 kernels would spill.
+  constexpr bool kHoldInputs = W == 2 && A::NL <= 9;
+  typename A::Fe insum[kHoldInputs ? C : 1];
+  if constexpr (kHoldInputs) {
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      insum[i] = st[i];
+#pragma unroll
+      for (int j = 1; j < K; j++) A::add(insum[i], insum[i], st[i + C * j]);
+    }
+  }
   permutation<F, A, W, WIN>(st, pc, make_table<A>(lds));
 #pragma unroll
   for (int i = 0; i < C; i++) {
@@ -159,15 +173,18 @@ ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out,
 #pragma unroll
     for (int j = 1; j < K; j++) A::add(sum[i], sum[i], st[i + C * j]);
   }
-  // Jive feed-forward: the inputs are fetched again (L2-resident, 96 B per item) instead of
-  // being held in 12-28 VGPRs across the whole permutation
-  __syncthreads();
-  block_load<PER>(lds, in, blk0, cnt);
-  static_for<0, W>([&](auto i) { lds_get<A>(lds, threadIdx.x * W + i, st[i]); });
+  if constexpr (kHoldInputs) {
 #pragma unroll
-  for (int i = 0; i < C; i++) {
+    for (int i = 0; i < C; i++) A::add(sum[i], sum[i], insum[i]);
+  } else {
+    __syncthreads();
+    block_load<PER>(lds, in, blk0, cnt);
+    static_for<0, W>([&](auto i) { lds_get<A>(lds, threadIdx.x * W + i, st[i]); });
 #pragma unroll
-    for (int j = 0; j < K; j++) A::add(sum[i], sum[i], st[i + C * j]);
+    for (int i = 0; i < C; i++) {
+#pragma unroll
+      for (int j = 0; j < K; j++) A::add(sum[i], sum[i], st[i + C * j]);
+    }
   }
   __syncthreads();
   static_for<0, C>([&](auto i) { lds_put<A>(lds, threadIdx.x * C + i, sum[i]); });
