@@ -354,3 +354,40 @@ print("ok")
         env = dict(os.environ, ANEMOI_COOP_MAX=coop_max)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "ok" in out.stdout, (coop_max, out.stdout[-1500:], out.stderr[-1500:])
+
+
+def test_concurrent_callers(A, oracle, params):
+    """The C-ABI is re-entrant: four host threads hammer different entry points (different fields,
+    so the lazily created per-device constant tables race too) and every result must be exact."""
+    import threading
+    fid_b, fid_j = FIELD_IDS.index("pallas"), FIELD_IDS.index("ed_on_bls12_377")
+    p_b, p_j = int(params["pallas"]["modulus"]), int(params["ed_on_bls12_377"]["modulus"])
+    st_b = rand_elems(oracle, fid_b, p_b, 2 * 3000, 1).reshape(3000, 2, 4)
+    st_j = rand_elems(oracle, fid_j, p_j, 4 * 900, 2).reshape(900, 4, 4)
+    msgs = np.random.default_rng(3).integers(0, 256, size=(200, 95), dtype=np.uint8)
+    exp_b = oracle.compress_batch(fid_b, 2, st_b, threads=8)
+    exp_j = oracle.compress_batch(fid_j, 4, st_j, threads=8)
+    exp_h = oracle.hash_bytes_batch(fid_j, 2, msgs, threads=8)
+    errors = []
+
+    def worker(kind):
+        try:
+            for _ in range(3):
+                if kind == 0:
+                    assert (A.Anemoi("pallas", 2).compress_batch(st_b) == exp_b).all()
+                elif kind == 1:
+                    assert (A.Anemoi("ed_on_bls12_377", 4).compress_batch(st_j) == exp_j).all()
+                elif kind == 2:
+                    assert (A.Anemoi("ed_on_bls12_377", 2).hash_batch(msgs) == exp_h).all()
+                else:
+                    assert (A.Anemoi("pallas", 2).merkle_root(st_b[:256, 0], 8)
+                            == oracle.merkle_root(fid_b, st_b[:256, 0], 8)).all()
+        except Exception as e:  # noqa: BLE001
+            errors.append((kind, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
