@@ -161,7 +161,7 @@ def main():
     if rank == 0:
         # HBM traffic and VALU utilisation come from the committed rocprofv3 --pmc passes of this same
         # command (profiles/rNN/pmc_k_jive.json): counters cannot be read from inside the process.
-        traffic, valu_busy, prof_src = None, None, None
+        traffic, valu_busy, mad_frac, prof_src = None, None, None, None
         try:
             prof_dirs = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r"))
             prof_src = os.path.join("profiles", prof_dirs[-1], "pmc_k_jive.json")
@@ -169,6 +169,7 @@ def main():
             if args.batch_log2 == BATCH_LOG2:
                 traffic = pmc["hbm_traffic_bytes_per_launch"]
             valu_busy = pmc["valu_busy_fraction"]
+            mad_frac = pmc.get("mad_issue_fraction_of_peak")
         except Exception:
             prof_src = None
         total_items = n * world * args.steps
@@ -190,6 +191,7 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_ITEM * n},
             "alu": {"bound": "valu", "modmul_per_s": MODMUL_PER_ITEM * n / (kernel_ms * 1e-3),
                     "valu_busy_frac_profiled": valu_busy,
+                    "mad_issue_frac_of_peak_profiled": mad_frac,
                     "note": "384-bit Montgomery mul/sqr per second (reference chain count 9576 per compression). "
                             "The path is VALU-issue bound: the profiled kernel keeps the vector ALUs busy in "
                             "valu_busy_frac_profiled of all SIMD cycles (SQ_ACTIVE_INST_VALU, profiles/), see DESIGN.md"},
