@@ -20,6 +20,15 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+// ANEMOI_ASM_MUL = 1: squaring / multiplication come from the generated hand-scheduled assembly
+// (mont29_asm_gen.h, tools/gen_asm_mul.py) instead of the C++ below.
+#ifndef ANEMOI_ASM_MUL
+#define ANEMOI_ASM_MUL 1
+#endif
+#if ANEMOI_ASM_MUL
+#include "mont29_asm_gen.h"
+#endif
+
 namespace anemoi {
 
 template <class F>
@@ -54,6 +63,12 @@ struct Arith29 {
   // Forcing a leaner schedule (fewer registers, 5-8 waves/SIMD) was measured and is slower: the
   // multiplier is bound by VALU issue, not by occupancy (profiles/r01/ab_occupancy_variants.txt).
   __device__ static __forceinline__ void mul(Fe& r, const Fe& a, const Fe& b) {
+#if ANEMOI_ASM_MUL
+    Fe t = a;
+    AsmMont29<F::kId>::mul(t.l, b.l);
+    r = t;
+    return;
+#endif
     uint32_t m[NL], out[NL];
     uint64_t acc = 0;
 #pragma unroll
@@ -72,6 +87,12 @@ struct Arith29 {
   // Montgomery square.  Off-diagonal products use a pre-doubled copy of a (limb-wise doubling is
   // exact with unsaturated limbs: 2*l[i] < 2^30), so each costs one multiply-accumulate.
   __device__ static __forceinline__ void sqr(Fe& r, const Fe& a) {
+#if ANEMOI_ASM_MUL
+    Fe t = a;
+    AsmMont29<F::kId>::sqr(t.l);
+    r = t;
+    return;
+#endif
     uint32_t m[NL], out[NL], a2[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;

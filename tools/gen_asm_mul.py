@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generate anemoi-rust_amd/csrc/mont29_asm_gen.h: the lane-private 29-bit-limb Montgomery
+squaring and multiplication of mont29.h as hand-scheduled gfx950 assembly, one `asm volatile`
+statement per product.
+
+Why: hipcc reassociates the C++ product scanning of mont29.h into an operand-scanning schedule that
+needs one extra 64-bit add per column and ~30 register moves per multiplication (412 / 537
+instructions per squaring / multiplication on 14 limbs).  The straight product-scanning form below
+carries the column carry as the accumulator's initial value: 383 / 474 instructions.  The kernels
+are bound by VALU issue (profiles/r01), so instructions are time.
+
+Form (NL limbs, column k of the 2 NL - 1 columns, accumulator ACC = 64-bit VGPR pair):
+    ACC += sum a_j * b_{k-j}          v_mad_u64_u32 (squaring: pre-doubled a2_j * a_{k-j}, j < k-j, + a_{k/2}^2)
+    ACC += sum m_j * p_{k-j}          v_mad_u64_u32 with p as SGPR operand
+    k <  NL:  m_k = (ACC.lo * n0inv) & MASK ; ACC += m_k * p_0
+    k >= NL:  out_{k-NL} = ACC.lo & MASK      (written over a_{k-NL}, dead by then)
+    ACC >>= 29
+No hazards need padding: only VALU -> VALU register dependences (interlocked), VCC is written (the
+unused carry-out of v_mad_u64_u32) but never read.
+
+Operand budget (inline asm allows 30): squaring = NL in/out VGPRs + NL SGPRs (p) + 1 SGPR (n0inv);
+multiplication = NL in/out + NL in VGPRs, so p and n0inv are loaded into clobbered SGPRs inside the
+statement (NL + 1 s_mov_b32).  Temporaries live in fixed clobbered VGPRs v[TMP_BASE ...].
+
+    python tools/gen_asm_mul.py
+"""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELD_IDS = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
+W = 29
+MASK = (1 << W) - 1
+TMP_BASE = 100      # clobbered VGPRs start here (even: the 64-bit accumulator must be 2-aligned)
+SGPR_BASE = 60      # clobbered SGPRs of the multiplication
+
+
+def field_consts(p):
+    nl = -(-(p.bit_length() + 6) // W)
+    limbs = [(p >> (W * i)) & MASK for i in range(nl)]
+    n0inv = (-pow(p, -1, 1 << W)) % (1 << W)
+    return nl, limbs, n0inv
+
+
+def gen_sqr(nl, plimbs, n0inv):
+    """operands: %0..%{nl-1} = a (in/out VGPR), %{nl}..%{2nl-1} = p limbs (SGPR), %{2nl} = n0inv (SGPR)"""
+    acc = TMP_BASE                 # v[acc:acc+1]
+    a2 = TMP_BASE + 2              # nl regs
+    m = a2 + nl                    # nl regs
+    A = lambda i: "%%%d" % i
+    P = lambda i: "%%%d" % (nl + i)
+    N0 = "%%%d" % (2 * nl)
+    ACC = "v[%d:%d]" % (acc, acc + 1)
+    out = []
+    for j in range(nl):
+        out.append("v_lshlrev_b32 v%d, 1, %s" % (a2 + j, A(j)))
+    out.append("v_mov_b32 v%d, 0" % acc)
+    out.append("v_mov_b32 v%d, 0" % (acc + 1))
+    for k in range(2 * nl - 1):
+        j0 = 0 if k < nl else k - nl + 1
+        j = j0
+        while j < k - j:
+            out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, a2 + j, A(k - j), ACC))
+            j += 1
+        if k % 2 == 0:
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, A(k // 2), A(k // 2), ACC))
+        if k < nl:
+            for j in range(k):
+                if plimbs[k - j]:
+                    out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + j, P(k - j), ACC))
+            if n0inv == MASK:   # p = 1 mod 2^29: m = -lo mod 2^29
+                out.append("v_sub_u32 v%d, 0, v%d" % (m + k, acc))
+            else:
+                out.append("v_mul_lo_u32 v%d, v%d, %s" % (m + k, acc, N0))
+            out.append("v_and_b32 v%d, 0x%x, v%d" % (m + k, MASK, m + k))
+            out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + k, P(0), ACC))
+        else:
+            for j in range(k - nl + 1, nl):
+                if plimbs[k - j]:
+                    out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + j, P(k - j), ACC))
+            out.append("v_and_b32 %s, 0x%x, v%d" % (A(k - nl), MASK, acc))   # a_{k-nl} is dead from here on
+        out.append("v_lshrrev_b64 %s, %d, %s" % (ACC, W, ACC))
+    out.append("v_mov_b32 %s, v%d" % (A(nl - 1), acc))
+    clob = ["v%d" % r for r in range(TMP_BASE, m + nl)] + ["vcc"]
+    return out, clob
+
+
+def gen_mul(nl, plimbs, n0inv):
+    """operands: %0..%{nl-1} = a (in/out VGPR), %{nl}..%{2nl-1} = b (VGPR)"""
+    acc = TMP_BASE
+    m = TMP_BASE + 2
+    A = lambda i: "%%%d" % i
+    B = lambda i: "%%%d" % (nl + i)
+    SP = lambda i: "s%d" % (SGPR_BASE + i)
+    SN0 = "s%d" % (SGPR_BASE + nl)
+    ACC = "v[%d:%d]" % (acc, acc + 1)
+    out = []
+    for i in range(nl):
+        out.append("s_mov_b32 %s, 0x%x" % (SP(i), plimbs[i]))
+    out.append("s_mov_b32 %s, 0x%x" % (SN0, n0inv))
+    out.append("v_mov_b32 v%d, 0" % acc)
+    out.append("v_mov_b32 v%d, 0" % (acc + 1))
+    for k in range(2 * nl - 1):
+        j0, j1 = (0, k) if k < nl else (k - nl + 1, nl - 1)
+        for j in range(j0, j1 + 1):
+            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, A(j), B(k - j), ACC))
+        if k < nl:
+            for j in range(k):
+                if plimbs[k - j]:
+                    out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + j, SP(k - j), ACC))
+            if n0inv == MASK:
+                out.append("v_sub_u32 v%d, 0, v%d" % (m + k, acc))
+            else:
+                out.append("v_mul_lo_u32 v%d, v%d, %s" % (m + k, acc, SN0))
+            out.append("v_and_b32 v%d, 0x%x, v%d" % (m + k, MASK, m + k))
+            out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + k, SP(0), ACC))
+        else:
+            for j in range(k - nl + 1, nl):
+                if plimbs[k - j]:
+                    out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + j, SP(k - j), ACC))
+            out.append("v_and_b32 %s, 0x%x, v%d" % (A(k - nl), MASK, acc))
+        out.append("v_lshrrev_b64 %s, %d, %s" % (ACC, W, ACC))
+    out.append("v_mov_b32 %s, v%d" % (A(nl - 1), acc))
+    clob = ["v%d" % r for r in range(TMP_BASE, m + nl)] + ["s%d" % (SGPR_BASE + i) for i in range(nl + 1)] + ["vcc"]
+    return out, clob
+
+
+def emit(name, lines, outs, ins, clob):
+    body = "\n".join('        "%s\\n\\t"' % l for l in lines)
+    return ("    asm volatile(\n%s\n        : %s\n        : %s\n        : %s);\n"
+            % (body, ", ".join(outs), ", ".join(ins) if ins else "", ", ".join('"%s"' % c for c in clob)))
+
+
+def main():
+    with open(os.path.join(ROOT, "tests", "golden", "params.json")) as f:
+        params = json.load(f)
+    h = ["// GENERATED by tools/gen_asm_mul.py -- do not edit.  Hand-scheduled gfx950 Montgomery squaring /",
+         "// multiplication on 29-bit limbs (product scanning, one v_mad_u64_u32 per limb product, the column",
+         "// carry is the accumulator's initial value).  See the generator's docstring.",
+         "#pragma once", "#include <hip/hip_runtime.h>", "#include <cstdint>", "namespace anemoi {",
+         "template <int FIELD> struct AsmMont29;"]
+    for fid, name in enumerate(FIELD_IDS):
+        p = int(params[name]["modulus"])
+        nl, pl, n0 = field_consts(p)
+        sq, sq_clob = gen_sqr(nl, pl, n0)
+        mu, mu_clob = gen_mul(nl, pl, n0)
+        nmad = sum(1 for l in sq if l.startswith("v_mad"))
+        h.append("// %s: %d limbs; squaring %d instructions (%d v_mad_u64_u32), multiplication %d (%d)" % (
+            name, nl, len(sq), nmad, len(mu), sum(1 for l in mu if l.startswith("v_mad"))))
+        h.append("template <> struct AsmMont29<%d> {" % fid)
+        h.append("  static constexpr int NL = %d;" % nl)
+        h.append("  __device__ static __forceinline__ void sqr(uint32_t (&a)[NL]) {")
+        outs = ['"+v"(a[%d])' % i for i in range(nl)]
+        ins = ['"s"(0x%xu)' % v for v in pl] + ['"s"(0x%xu)' % n0]
+        h.append(emit("sqr", sq, outs, ins, sq_clob))
+        h.append("  }")
+        h.append("  __device__ static __forceinline__ void mul(uint32_t (&a)[NL], const uint32_t (&b)[NL]) {")
+        ins = ['"v"(b[%d])' % i for i in range(nl)]
+        h.append(emit("mul", mu, outs, ins, mu_clob))
+        h.append("  }")
+        h.append("};")
+    h.append("}  // namespace anemoi")
+    dst = os.path.join(ROOT, "anemoi-rust_amd", "csrc", "mont29_asm_gen.h")
+    with open(dst, "w") as f:
+        f.write("\n".join(h) + "\n")
+    print("wrote", dst)
+
+
+if __name__ == "__main__":
+    main()
