@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""One-off differential fuzz: many random and structured states per field through the GPU kernels
+(lane-private and wave-cooperative Jive 2-1, Jive 4-3, permutation) against the C oracle.
+Structured states stress carry patterns: limbs of all ones, values next to p and to 2^k, sparse values.
+    python tools/fuzz_gpu_vs_oracle.py [items_per_field]"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "anemoi-rust_amd")):
+    sys.path.insert(0, p)
+import json
+import numpy as np
+import orc
+import anemoi_amd as A
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+params = json.load(open(os.path.join(ROOT, "tests", "golden", "params.json")))
+oracle = orc.Oracle()
+threads = 16
+bad = 0
+for fid, field in enumerate(A.FIELD_IDS):
+    p, L = int(params[field]["modulus"]), params[field]["u64_limbs"]
+    rng = random.Random(1000 + fid)
+    vals = []
+    bits = p.bit_length()
+    for k in range(0, bits, 7):
+        for d in (-2, -1, 0, 1, 2):
+            vals.append(((1 << k) + d) % p)
+            vals.append((p - (1 << k) + d) % p)
+    vals += [((1 << bits) - 1) % p, (1 << (bits - 1)) % p, p - 1, p - 2, 0, 1, 2]
+    for w in (29, 32, 58, 64):
+        ones = 0
+        for i in range(0, bits, 2 * w):
+            ones |= ((1 << w) - 1) << i
+        vals += [ones % p, (ones << w) % p]
+    structured = vals
+    for width in (2, 4):
+        cnt = n if width == 2 else n // 4
+        items = []
+        for i in range(cnt):
+            if i < len(structured):
+                st = [structured[(i + j * 17) % len(structured)] for j in range(width)]
+            else:
+                st = [rng.randrange(p) for _ in range(width)]
+            items.extend(st)
+        st = oracle.ints_to_mont(fid, items).reshape(cnt, width, L)
+        inst = A.Anemoi(field, width)
+        exp = oracle.compress_batch(fid, width, st, threads=threads)
+        got = inst.compress_batch(st)
+        ok = (got == exp).all()
+        msg = "%-16s W=%d compress %6d items: %s" % (field, width, cnt, "ok" if ok else "MISMATCH")
+        if width == 2:  # force the other kernel too on a slice
+            small = st[:1500]
+            ok2 = (inst.compress_batch(small) == exp[:1500]).all()  # <= 2048 -> cooperative kernel
+            msg += "  coop(1500): %s" % ("ok" if ok2 else "MISMATCH")
+            ok = ok and ok2
+        pg = inst.permutation_batch(st[:256])
+        ok3 = all((pg[i] == oracle.permutation(fid, width, st[i])).all() for i in range(0, 256, 5))
+        msg += "  permutation: %s" % ("ok" if ok3 else "MISMATCH")
+        print(msg, flush=True)
+        bad += 0 if (ok and ok3) else 1
+print("FUZZ", "FAILED" if bad else "PASSED")
+sys.exit(1 if bad else 0)

@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELD_IDS = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
 W = 29
 MASK = (1 << W) - 1
-TMP_BASE = 100      # clobbered VGPRs start here (even: the 64-bit accumulator must be 2-aligned)
+TMP_BASE = int(os.environ.get("ANEMOI_ASM_TMP_BASE", "100"))  # clobbered VGPRs start here (even: the 64-bit accumulator is 2-aligned)
 SGPR_BASE = 60      # clobbered SGPRs of the multiplication
 
 
