@@ -50,9 +50,7 @@ impl Jive<Felt> for AnemoiBls12_381_2_1 {
             // callers with many states use compress_batch.
         }
 
-        let mut state = elems.to_vec();
-        AnemoiBls12_381_2_1::permutation(&mut state);
-        vec![state[0] + state[1] + elems[0] + elems[1]]
+        reference_cpu_compress(elems) // the unchanged body of hasher.rs:99-102, moved into a helper
     }
 
     fn compress_k(elems: &[Felt], k: usize) -> Vec<Felt> {
