@@ -6,6 +6,8 @@
 //   k_sponge        Sponge::hash / hash_field          src/<f>/anemoi_2_1/hasher.rs:18-85, anemoi_4_3/hasher.rs:19-129
 //   k_merkle_climb  authentication-path verification   (depth x Sponge::merge, anemoi_2_1/hasher.rs:87-92)
 //   k_mont_convert  canonical <-> Montgomery           (arkworks into_bigint / from_bigint)
+// one Anemoi-4-3 state per lane PAIR (both columns' S-boxes run side by side):
+//   k_permutation_pair, k_jive_pair, k_sponge_pair      (all width-4 entry points)
 // one item per wavefront (latency path, small batches):
 //   k_jive2_coop    Jive::compress 2-1 / Sponge::merge on the wave-cooperative arithmetic of coop29.h
 //
@@ -268,6 +270,131 @@ ANEMOI_KERNEL void k_sponge(const void* __restrict__ src, size_t per_msg, size_t
   block_store<A::NABI / 4>(lds, out, blk0, cnt);
 }
 
+// ---- Anemoi-4-3 kernels with one state per lane PAIR (anemoi_perm.h, "two columns on two lanes") -------
+// A workgroup of 64 lanes owns 32 states; lane t works on state t/2, column t%2.
+constexpr int kPairStates = kBlock / 2;
+
+template <int FIELD, bool SBOX_ONLY>
+ANEMOI_KERNEL void k_permutation_pair(uint4* __restrict__ states, size_t n, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using A = ArithFor<FIELD>;
+  constexpr int WIN = KernelCfg<F::N>::WIN, PER = 2 * A::NABI / 4;  // uint4 per lane
+  extern __shared__ uint4 lds[];
+  const size_t st0 = size_t(blockIdx.x) * kPairStates;
+  const int cnt = n - st0 < size_t(kPairStates) ? int(n - st0) : kPairStates;
+  const bool odd = threadIdx.x & 1;
+  const int s = threadIdx.x >> 1;
+  block_load<PER>(lds, states, size_t(blockIdx.x) * kBlock, 2 * cnt);
+  typename A::Fe x, y;
+  lds_get<A>(lds, s * 4 + (odd ? 1 : 0), x);
+  lds_get<A>(lds, s * 4 + 2 + (odd ? 1 : 0), y);
+  __syncthreads();
+  if (SBOX_ONLY) flystel<F, A, WIN>(x, y, pc, make_table<A>(lds));
+  else permutation_pair<F, A, WIN>(x, y, odd, pc, make_table<A>(lds));
+  __syncthreads();
+  lds_put<A>(lds, s * 4 + (odd ? 1 : 0), x);
+  lds_put<A>(lds, s * 4 + 2 + (odd ? 1 : 0), y);
+  block_store<PER>(lds, states, size_t(blockIdx.x) * kBlock, 2 * cnt);
+}
+
+// Jive on Anemoi-4-3 (anemoi_4_3/hasher.rs:148-179).  K = 2: out[i] = e_i + e_{i+2} + s_i + s_{i+2}, i.e.
+// lane-local (x_in + y_in + x_out + y_out); K = 4: the two lanes' sums are added.
+template <int FIELD, int K>
+ANEMOI_KERNEL void k_jive_pair(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using A = ArithFor<FIELD>;
+  constexpr int WIN = KernelCfg<F::N>::WIN, PER = 2 * A::NABI / 4;
+  extern __shared__ uint4 lds[];
+  const size_t st0 = size_t(blockIdx.x) * kPairStates;
+  const int cnt = n - st0 < size_t(kPairStates) ? int(n - st0) : kPairStates;
+  const bool odd = threadIdx.x & 1;
+  const int s = threadIdx.x >> 1;
+  block_load<PER>(lds, in, size_t(blockIdx.x) * kBlock, 2 * cnt);
+  typename A::Fe x, y, sum, t;
+  lds_get<A>(lds, s * 4 + (odd ? 1 : 0), x);
+  lds_get<A>(lds, s * 4 + 2 + (odd ? 1 : 0), y);
+  __syncthreads();
+  A::add(sum, x, y);  // feed-forward part, one element per lane, kept in registers
+  permutation_pair<F, A, WIN>(x, y, odd, pc, make_table<A>(lds));
+  A::add(t, x, y);
+  A::add(sum, sum, t);
+  __syncthreads();
+  if (K == 2) {
+    lds_put<A>(lds, s * 2 + (odd ? 1 : 0), sum);
+    block_store<A::NABI / 4>(lds, out, size_t(blockIdx.x) * kBlock, 2 * cnt);
+  } else {
+    fe_exchange<A>(t, sum);
+    A::add(sum, sum, t);
+    if (A::kLoose) A::settle(sum);
+    // only the even lane's copy is stored (both lanes hold the same total)
+    typename A::Fe dummy = sum;
+    if (!odd) lds_put<A>(lds, s, dummy);
+    else lds_put<A>(lds, kPairStates + s, dummy);  // scratch slots beyond the 32 outputs
+    block_store<A::NABI / 4>(lds, out, st0, cnt);
+  }
+}
+
+// Sponge on Anemoi-4-3 (anemoi_4_3/hasher.rs:19-129), one message per lane pair: both lanes decode
+// the same element, the lane that owns state[pos] absorbs it (state[0], state[1] = x of the even / odd
+// lane, state[2] = y of the even lane).
+template <int FIELD, bool BYTES>
+ANEMOI_KERNEL void k_sponge_pair(const void* __restrict__ src, size_t per_msg, size_t n, uint4* __restrict__ out,
+                                 PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using A = ArithFor<FIELD>;
+  constexpr int WIN = KernelCfg<F::N>::WIN, RATE = 3;
+  extern __shared__ uint4 lds[];
+  const size_t st0 = size_t(blockIdx.x) * kPairStates;
+  const int cnt = n - st0 < size_t(kPairStates) ? int(n - st0) : kPairStates;
+  const bool odd = threadIdx.x & 1;
+  const int s = threadIdx.x >> 1;
+  const size_t item = st0 + (s < cnt ? s : 0);  // idle lane pairs redo item st0
+  const size_t num = BYTES ? (per_msg + F::kChunk - 1) / F::kChunk : per_msg;
+  const size_t total = num + (num % RATE == 0 ? 0 : 1);
+  const uint8_t* msg = (const uint8_t*)src + (BYTES ? item * per_msg : item * per_msg * A::NABI * 4);
+  typename A::Fe x, y;
+  A::set_zero(x);
+  A::set_zero(y);
+  int pos = 0;
+  const LdsTable<A> tab = make_table<A>(lds);
+#pragma nounroll
+  for (size_t e = 0; e < total; e++) {
+    typename A::Fe el, t;
+    if (e < num) {
+      if (BYTES) {
+        const size_t off = e * F::kChunk;
+        const size_t left = per_msg - off;
+        chunk_to_fe<F, A>(el, msg + off, left < size_t(F::kChunk) ? int(left) : F::kChunk);
+      } else {
+        const uint32_t* src32 = (const uint32_t*)msg + e * A::NABI;
+        uint32_t w[A::NABI];
+#pragma unroll
+        for (int l = 0; l < A::NABI; l++) w[l] = src32[l];
+        A::from_abi(el, w);
+      }
+    } else {
+      A::set_one(el);
+    }
+    // pos is wave-uniform: state[0] -> even.x, state[1] -> odd.x, state[2] -> even.y
+    if (pos < 2) {
+      A::add(t, x, el);
+      fe_select<A>(x, odd == (pos == 1), t, x);
+    } else {
+      A::add(t, y, el);
+      fe_select<A>(y, !odd, t, y);
+    }
+    pos++;
+    if (pos == RATE || e == total - 1) {
+      permutation_pair<F, A, WIN>(x, y, odd, pc, tab);
+      pos = 0;
+    }
+  }
+  __syncthreads();
+  // digest = state[0] = the even lane's x; odd lanes write to scratch slots beyond the outputs
+  lds_put<A>(lds, odd ? kPairStates + s : s, x);
+  block_store<A::NABI / 4>(lds, out, st0, cnt);
+}
+
 // Merkle authentication: lane i hashes leaf i up its path (depth sibling digests, bottom-up) with
 // the 2-1 instance's merge (= Jive compress of [left, right], anemoi_2_1/hasher.rs:87-92) and writes
 // the recomputed root; bit l of index[i] says whether the node is the right child at level l.
@@ -442,6 +569,7 @@ struct FieldOps {
 const FieldOps* field_ops(int field);  // capi.hip
 
 inline unsigned grid_for(size_t n) { return unsigned((n + kBlock - 1) / kBlock); }
+inline unsigned pair_grid(size_t n) { return unsigned((n + kBlock / 2 - 1) / (kBlock / 2)); }  // 32 states per workgroup
 
 template <int FIELD>
 struct Launch {
@@ -480,9 +608,9 @@ struct Launch {
     else if (width == 2)
       k_permutation<FIELD, 2, true><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((uint4*)d, n, pc);
     else if (!sbox_only)
-      k_permutation<FIELD, 4, false><<<grid_for(n), kBlock, lds_bytes<A, WIN, 4>(), s>>>((uint4*)d, n, pc);
+      k_permutation_pair<FIELD, false><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((uint4*)d, n, pc);
     else
-      k_permutation<FIELD, 4, true><<<grid_for(n), kBlock, lds_bytes<A, WIN, 4>(), s>>>((uint4*)d, n, pc);
+      k_permutation_pair<FIELD, true><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((uint4*)d, n, pc);
     return hipGetLastError();
   }
 
@@ -496,9 +624,9 @@ struct Launch {
     if (width == 2)
       k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     else if (k == 2)
-      k_jive<FIELD, 4, 2><<<grid_for(n), kBlock, lds_bytes<A, WIN, 4>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+      k_jive_pair<FIELD, 2><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     else
-      k_jive<FIELD, 4, 4><<<grid_for(n), kBlock, lds_bytes<A, WIN, 4>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+      k_jive_pair<FIELD, 4><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     return hipGetLastError();
   }
 
@@ -511,9 +639,9 @@ struct Launch {
     else if (width == 2)
       k_sponge<FIELD, 2, false><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc);
     else if (bytes)
-      k_sponge<FIELD, 4, true><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc);
+      k_sponge_pair<FIELD, true><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(src, per_msg, n, (uint4*)out, pc);
     else
-      k_sponge<FIELD, 4, false><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc);
+      k_sponge_pair<FIELD, false><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(src, per_msg, n, (uint4*)out, pc);
     return hipGetLastError();
   }
 

@@ -194,4 +194,71 @@ __device__ __forceinline__ void permutation(typename A::Fe (&st)[W], const PermC
   mds_layer<F, A, W>(st);
 }
 
+// ---- Anemoi-4-3 with the two columns of a state on two adjacent lanes ------------------------------
+// Lane 2i holds (x0, y0) = (state[0], state[2]) of state i, lane 2i+1 holds (x1, y1) = (state[1],
+// state[3]).  The two S-boxes of a round (99 % of the work) are independent, so a state advances on
+// two lanes at once: half the latency per permutation and twice the wavefronts for a given batch,
+// which is what small batches need (one wavefront alone issues only one VALU instruction per ~6
+// cycles).  Only the linear layer couples the columns; it exchanges values with the neighbour lane
+// through DPP quad_perm:[1,0,3,2].
+template <class A>
+__device__ __forceinline__ void fe_exchange(typename A::Fe& out, const typename A::Fe& in) {
+#pragma unroll
+  for (int i = 0; i < A::NL; i++)
+    out.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)in.l[i], 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+}
+
+template <class A>
+__device__ __forceinline__ void fe_select(typename A::Fe& r, bool take_a, const typename A::Fe& a,
+                                          const typename A::Fe& b) {
+#pragma unroll
+  for (int i = 0; i < A::NL; i++) r.l[i] = take_a ? a.l[i] : b.l[i];
+}
+
+// mds_layer arm NUM_COLUMNS = 2 (src/traits.rs:143-157), statement by statement:
+//   s0 += g s1 ; s1 += g s0 ; s3 += g s2 ; s2 += g s3 ; swap(s2, s3) ; s2 += s0 ; s3 += s1 ; s0 += s2 ; s1 += s3
+template <class F, class A>
+__device__ __forceinline__ void mds_pair(typename A::Fe& x, typename A::Fe& y, bool odd) {
+  typename A::Fe p, t, s;
+  fe_exchange<A>(p, x);  // even lanes: s0 += g * s1
+  A::mul_g(t, p);
+  A::add(s, x, t);
+  fe_select<A>(x, !odd, s, x);
+  fe_exchange<A>(p, x);  // odd lanes: s1 += g * s0 (the updated one)
+  A::mul_g(t, p);
+  A::add(s, x, t);
+  fe_select<A>(x, odd, s, x);
+  fe_exchange<A>(p, y);  // odd lanes: s3 += g * s2
+  A::mul_g(t, p);
+  A::add(s, y, t);
+  fe_select<A>(y, odd, s, y);
+  fe_exchange<A>(p, y);  // even lanes: s2 += g * s3 (the updated one)
+  A::mul_g(t, p);
+  A::add(s, y, t);
+  fe_select<A>(y, !odd, s, y);
+  fe_exchange<A>(p, y);  // swap(s2, s3)
+  y = p;
+  A::add(y, y, x);  // s2 += s0 ; s3 += s1
+  A::add(x, x, y);  // s0 += s2 ; s1 += s3
+  if (A::kLoose) {
+    A::settle(x);
+    A::settle(y);
+  }
+}
+
+template <class F, class A, int WIN>
+__device__ __forceinline__ void permutation_pair(typename A::Fe& x, typename A::Fe& y, bool odd, const PermConsts& pc,
+                                                 const LdsTable<A>& tab) {
+  constexpr int R = F::kRounds43;
+  const int col = odd ? 1 : 0;
+#pragma nounroll
+  for (int r = 0; r < R; r++) {
+    add_global<A>(x, pc.ark_c + (r * 2 + col) * A::NL);
+    add_global<A>(y, pc.ark_d + (r * 2 + col) * A::NL);
+    mds_pair<F, A>(x, y, odd);
+    flystel<F, A, WIN>(x, y, pc, tab);
+  }
+  mds_pair<F, A>(x, y, odd);
+}
+
 }  // namespace anemoi
