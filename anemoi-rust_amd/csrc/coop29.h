@@ -74,6 +74,7 @@ struct Coop29 {
   // Montgomery product (limbs of a, b < 2^29 + 2^7): result < 2p when (a/p)(b/p) <= R'/p
   __device__ static __forceinline__ uint32_t mul(uint32_t a, uint32_t b, uint32_t pl) {
     uint64_t t = 0;
+    const uint32_t sh = lane() == 0 ? 29u : 63u;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const uint32_t ai = __builtin_amdgcn_readlane(a, i);
@@ -81,7 +82,10 @@ struct Coop29 {
       const uint32_t t0 = __builtin_amdgcn_readlane((uint32_t)t, 0);
       const uint32_t m = (t0 * F::kN0Inv29) & MASK;
       t += (uint64_t)m * pl;
-      const uint64_t u = lane() == 0 ? (t >> 29) : 0ull;
+      // lane 0's column is now 0 mod 2^29 and retires: its upper bits are the carry into the next
+      // column.  Every column sum stays < 2^63, so shifting by 63 yields 0 in all other lanes:
+      // a per-lane shift amount replaces a mask.
+      const uint64_t u = t >> sh;
       t = (((uint64_t)from_next((uint32_t)(t >> 32)) << 32) | from_next((uint32_t)t)) + u;
     }
     return settle_columns(t);
