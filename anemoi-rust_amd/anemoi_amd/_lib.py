@@ -46,6 +46,14 @@ def _load():
 
 lib = _load()
 
+class _GenericInstance(ctypes.Structure):
+    """struct anemoi_generic_instance (include/anemoi_mi355x.h)"""
+    _fields_ = [("field", _int), ("num_columns", _int), ("num_rounds", _int),
+                ("ark_c", _u64p), ("ark_d", _u64p), ("mds", _u64p)]
+
+
+_gip = ctypes.POINTER(_GenericInstance)
+
 _SIGS = {
     "anemoi_abi_version": ([], _int),
     "anemoi_device_count": ([], _int),
@@ -79,6 +87,12 @@ _SIGS = {
     "anemoi_hash_bytes_dev": ([_int, _int, _vp, _sz, _sz, _vp, _vp], _int),
     "anemoi_merkle_root_dev": ([_int, _vp, ctypes.c_uint, _vp, _vp, _vp], _int),
     "anemoi_to_montgomery_dev": ([_int, _vp, _vp, _sz, _vp], _int),
+    "anemoi_generic_mds_matrix": ([_int, _int, _u64p, _int], _int),
+    "anemoi_generic_permutation_batch": ([_gip, _u64p, _sz, _int], _int),
+    "anemoi_generic_jive_compress_k_batch": ([_gip, _int, _u64p, _u64p, _sz, _int], _int),
+    "anemoi_generic_hash_field_batch": ([_gip, _int, _u64p, _sz, _sz, _u64p, _int], _int),
+    "anemoi_generic_hash_bytes_batch": ([_gip, _int, _u8p, _sz, _sz, _u64p, _int], _int),
+    "anemoi_exp_alpha_batch": ([_int, _int, _u64p, _sz, _int], _int),
     "anemoi_from_montgomery_dev": ([_int, _vp, _vp, _sz, _vp], _int),
 }
 for _name, (_args, _res) in _SIGS.items():
@@ -317,3 +331,76 @@ class Anemoi:
         """AnemoiDigest::to_bytes (digest.rs:42-46): canonical little-endian bytes."""
         d = np.asarray(digest, dtype=np.uint64).reshape(1, self.limbs)
         return from_montgomery(self.field, d, self.device if self.device >= 0 else 0).tobytes()
+
+
+def exp_alpha_batch(field, elems, inverse=False, device=0):
+    """element-wise x^ALPHA (exp_by_alpha, src/traits.rs:94-104) or x^(1/ALPHA) (exp_by_inv_alpha)"""
+    fid = field_id(field)
+    limbs = lib.anemoi_field_limbs(fid)
+    if limbs < 0:
+        raise AnemoiError(-1)
+    e = np.ascontiguousarray(elems, dtype=np.uint64).reshape(-1, limbs).copy()
+    _check(lib.anemoi_exp_alpha_batch(fid, 1 if inverse else 0, _p64(e) if e.size else None, len(e), device))
+    return e
+
+
+def builtin_mds_matrix(field, num_columns, device=0):
+    """the matrix of the reference's hard-coded mds_layer arm for 1..6 columns (Montgomery rows)"""
+    fid = field_id(field)
+    limbs = lib.anemoi_field_limbs(fid)
+    if limbs < 0:
+        raise AnemoiError(-1)
+    out = np.zeros((max(num_columns, 0) ** 2, limbs), dtype=np.uint64)
+    _check(lib.anemoi_generic_mds_matrix(fid, num_columns, _p64(out) if out.size else None, device))
+    return out
+
+
+class GenericAnemoi:
+    """An Anemoi instance described by its trait constants (src/traits.rs:36-76): NUM_COLUMNS, NUM_ROUNDS,
+    ARK_C, ARK_D and optionally an MDS matrix (None = the reference's hard-coded arm, <= 6 columns).
+    Constants are Montgomery limb rows."""
+
+    def __init__(self, field, num_columns, num_rounds, ark_c, ark_d, mds=None, device=0):
+        self.field = field_id(field)
+        self.limbs = lib.anemoi_field_limbs(self.field)
+        if self.limbs < 0:
+            raise AnemoiError(-1)
+        self.num_columns, self.num_rounds, self.device = num_columns, num_rounds, device
+        self.width = 2 * num_columns
+        self._c = np.ascontiguousarray(ark_c, dtype=np.uint64).reshape(-1, self.limbs)
+        self._d = np.ascontiguousarray(ark_d, dtype=np.uint64).reshape(-1, self.limbs)
+        self._m = None if mds is None else np.ascontiguousarray(mds, dtype=np.uint64).reshape(-1, self.limbs)
+        if len(self._c) != num_columns * num_rounds or len(self._d) != len(self._c):
+            raise AnemoiError(-3)
+        if self._m is not None and len(self._m) != num_columns * num_columns:
+            raise AnemoiError(-3)
+        self._inst = _GenericInstance(self.field, num_columns, num_rounds, _p64(self._c), _p64(self._d),
+                                      _p64(self._m) if self._m is not None else None)
+
+    def permutation_batch(self, states):
+        s = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, self.width, self.limbs).copy()
+        _check(lib.anemoi_generic_permutation_batch(ctypes.byref(self._inst), _p64(s), len(s), self.device))
+        return s
+
+    def compress_k_batch(self, states, k):
+        s = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, self.width, self.limbs)
+        out = np.empty((len(s), self.width // k if k > 0 and self.width % k == 0 else 1, self.limbs), dtype=np.uint64)
+        _check(lib.anemoi_generic_jive_compress_k_batch(ctypes.byref(self._inst), k, _p64(s), _p64(out), len(s),
+                                                        self.device))
+        return out
+
+    def hash_field_batch(self, elems, rate):
+        e = np.ascontiguousarray(elems, dtype=np.uint64)
+        assert e.ndim == 3 and e.shape[2] == self.limbs, "expected [n][elems_per_msg][limbs]"
+        out = np.empty((e.shape[0], self.limbs), dtype=np.uint64)
+        _check(lib.anemoi_generic_hash_field_batch(ctypes.byref(self._inst), rate, _p64(e) if e.size else None,
+                                                   e.shape[1], e.shape[0], _p64(out), self.device))
+        return out
+
+    def hash_batch(self, msgs, rate):
+        m = np.ascontiguousarray(msgs, dtype=np.uint8)
+        assert m.ndim == 2, "expected [n][msg_len] bytes"
+        out = np.empty((m.shape[0], self.limbs), dtype=np.uint64)
+        _check(lib.anemoi_generic_hash_bytes_batch(ctypes.byref(self._inst), rate, _p8(m) if m.size else None,
+                                                   m.shape[1], m.shape[0], _p64(out), self.device))
+        return out

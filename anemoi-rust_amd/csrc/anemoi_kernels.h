@@ -10,6 +10,8 @@
 //   k_permutation_pair, k_jive_pair, k_sponge_pair      (all width-4 entry points)
 // one item per wavefront (latency path, small batches):
 //   k_jive2_coop    Jive::compress 2-1 / Sponge::merge on the wave-cooperative arithmetic of coop29.h
+// instances given by run-time trait constants, one state per NUM_COLUMNS lanes (anemoi_generic.h):
+//   k_permutation_cols, k_jive_cols, k_sponge_cols, and the element-wise k_exp_alpha
 //
 // Data layout in HBM: array-of-states, each state `W` elements of N 32-bit limbs (= the reference's
 // `&[Felt]` bytes).  A workgroup's states are contiguous, so it moves them with 16-byte-per-lane
@@ -545,6 +547,10 @@ __global__ __launch_bounds__(kBlock) void k_mont_convert(const uint4* __restrict
   block_store<N / 4>(lds, out, blk0, cnt);
 }
 
+}  // namespace anemoi
+#include "anemoi_generic.h"
+namespace anemoi {
+
 // ---- launchers (one set per field translation unit) ------------------------------------------------
 
 struct HostConsts {  // what the context uploads for one (field, width)
@@ -554,7 +560,7 @@ struct HostConsts {  // what the context uploads for one (field, width)
 };
 
 struct FieldOps {
-  int limbs64, chunk, rounds21, rounds43;
+  int limbs64, chunk, rounds21, rounds43, generator, alpha;
   const char* name;
   void (*host_consts)(int width, HostConsts* out);
   hipError_t (*permutation)(int width, int sbox_only, void* d_states, size_t n, PermConsts pc, hipStream_t s);
@@ -564,6 +570,13 @@ struct FieldOps {
   hipError_t (*mont_convert)(int to, const void* d_in, void* d_out, size_t count, hipStream_t s);
   hipError_t (*merkle_climb)(const void* d_leaves, const void* d_index, const void* d_paths, unsigned depth, size_t n,
                              void* d_out, PermConsts pc, hipStream_t s);
+  // run-time instances (anemoi_generic.h)
+  hipError_t (*generic_permutation)(void* d_states, size_t n, GenericConsts gc, PermConsts pc, hipStream_t s);
+  hipError_t (*generic_jive)(const void* d_in, void* d_out, size_t n, int k, GenericConsts gc, PermConsts pc,
+                             hipStream_t s);
+  hipError_t (*generic_sponge)(int bytes, const void* d_src, size_t per_msg, size_t n, void* d_out, int rate,
+                               GenericConsts gc, PermConsts pc, hipStream_t s);
+  hipError_t (*exp_alpha)(int inverse, void* d_elems, size_t n, PermConsts pc, hipStream_t s);
 };
 
 const FieldOps* field_ops(int field);  // capi.hip
@@ -659,9 +672,42 @@ struct Launch {
     return hipGetLastError();
   }
 
+  static hipError_t generic_permutation(void* d, size_t n, GenericConsts gc, PermConsts pc, hipStream_t s) {
+    if (!n) return hipSuccess;
+    k_permutation_cols<FIELD><<<cols_grid(n, gc.cols), kBlock, lds_bytes<A, WIN, 1>(), s>>>((uint32_t*)d, n, gc, pc);
+    return hipGetLastError();
+  }
+
+  static hipError_t generic_jive(const void* in, void* out, size_t n, int k, GenericConsts gc, PermConsts pc,
+                                 hipStream_t s) {
+    if (!n) return hipSuccess;
+    k_jive_cols<FIELD><<<cols_grid(n, gc.cols), kBlock, lds_bytes<A, WIN, 1>(), s>>>((const uint32_t*)in, (uint32_t*)out,
+                                                                                      n, k, gc, pc);
+    return hipGetLastError();
+  }
+
+  static hipError_t generic_sponge(int bytes, const void* src, size_t per_msg, size_t n, void* out, int rate,
+                                   GenericConsts gc, PermConsts pc, hipStream_t s) {
+    if (!n) return hipSuccess;
+    const unsigned g = cols_grid(n, gc.cols);
+    if (bytes)
+      k_sponge_cols<FIELD, true><<<g, kBlock, lds_bytes<A, WIN, 1>(), s>>>(src, per_msg, n, (uint32_t*)out, rate, gc, pc);
+    else
+      k_sponge_cols<FIELD, false><<<g, kBlock, lds_bytes<A, WIN, 1>(), s>>>(src, per_msg, n, (uint32_t*)out, rate, gc, pc);
+    return hipGetLastError();
+  }
+
+  static hipError_t exp_alpha(int inverse, void* d, size_t n, PermConsts pc, hipStream_t s) {
+    if (!n) return hipSuccess;
+    if (inverse) k_exp_alpha<FIELD, true><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>((uint4*)d, n, pc);
+    else k_exp_alpha<FIELD, false><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>((uint4*)d, n, pc);
+    return hipGetLastError();
+  }
+
   static const FieldOps* ops() {
-    static const FieldOps o{F::L64,      F::kChunk,   F::kRounds21, F::kRounds43, F::kName,     host_consts,
-                            permutation, jive,        sponge,       mont_convert, merkle_climb};
+    static const FieldOps o{F::L64,       F::kChunk,    F::kRounds21,        F::kRounds43, F::kG, F::kAlpha, F::kName,
+                            host_consts,  permutation,  jive,                sponge,       mont_convert,
+                            merkle_climb, generic_permutation, generic_jive, generic_sponge, exp_alpha};
     return &o;
   }
 };

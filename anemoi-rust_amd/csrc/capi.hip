@@ -230,6 +230,124 @@ int host_batch(int device, size_t n, const void* in, size_t in_per_item, void* o
   });
 }
 
+// ---- run-time instances (anemoi_generic.h) ---------------------------------------------------------
+
+// The matrix a hard-coded mds_layer arm applies to each half of the state, as small integers: the arm's
+// statements (src/traits.rs:136-279; mds_internal :307-323) applied to the unit vectors.
+bool builtin_mds(int c, uint64_t g, std::vector<uint64_t>* m) {
+  if (c < 1 || c > 6) return false;
+  m->assign(size_t(c) * c, 0);
+  for (int j = 0; j < c; j++) {
+    uint64_t s[6] = {0, 0, 0, 0, 0, 0}, o[6];
+    s[j] = 1;
+    switch (c) {
+      case 1: o[0] = s[0]; break;
+      case 2:
+        s[0] += g * s[1];
+        s[1] += g * s[0];
+        o[0] = s[0], o[1] = s[1];
+        break;
+      case 3: {
+        const uint64_t tmp = s[0] + g * s[2];
+        s[2] += s[1];
+        s[2] += g * s[0];
+        s[0] = tmp + s[2];
+        s[1] += tmp;
+        o[0] = s[0], o[1] = s[1], o[2] = s[2];
+        break;
+      }
+      case 4:
+        s[0] += s[1];
+        s[2] += s[3];
+        s[3] += g * s[0];
+        s[1] = g * (s[1] + s[2]);
+        s[0] += s[1];
+        s[2] += g * s[3];
+        s[1] += s[2];
+        s[3] += s[0];
+        for (int i = 0; i < 4; i++) o[i] = s[i];
+        break;
+      case 5: {
+        const uint64_t tot = s[0] + s[1] + s[2] + s[3] + s[4];
+        for (int i = 0; i < 5; i++)
+          o[i] = tot + s[(i + 3) % 5] + 2 * (s[(i + 2) % 5] + s[(i + 3) % 5] + 2 * s[(i + 4) % 5]);
+        break;
+      }
+      default: {
+        const uint64_t tot = s[0] + s[1] + s[2] + s[3] + s[4] + s[5];
+        for (int i = 0; i < 6; i++)
+          o[i] = tot + s[(i + 3) % 6] + s[(i + 5) % 6] +
+                 2 * (s[(i + 2) % 6] + s[(i + 3) % 6] + 2 * (s[(i + 4) % 6] + s[(i + 5) % 6]));
+        break;
+      }
+    }
+    for (int i = 0; i < c; i++) (*m)[size_t(i) * c + j] = o[i];
+  }
+  return true;
+}
+
+int check_generic(const anemoi_generic_instance* inst) {
+  if (!inst) return ANEMOI_ERR_ARG;
+  if (!anemoi::field_ops(inst->field)) return ANEMOI_ERR_FIELD;
+  if (inst->num_columns < 1 || inst->num_columns > ANEMOI_MAX_GENERIC_COLUMNS) return ANEMOI_ERR_WIDTH;
+  if (inst->num_rounds < 1 || inst->num_rounds > 255 || !inst->ark_c || !inst->ark_d) return ANEMOI_ERR_ARG;
+  if (!inst->mds && inst->num_columns > 6) return ANEMOI_ERR_ARG;  // "NO MDS matrix specified for this instance."
+  return ANEMOI_OK;
+}
+
+// Uploads an instance's constants to the current device (stream-ordered on the default stream).
+int upload_generic(const anemoi_generic_instance* inst, DevBuf* blob, anemoi::GenericConsts* gc) {
+  const FieldOps* ops = anemoi::field_ops(inst->field);
+  const size_t eb = elem_bytes(inst->field), c = size_t(inst->num_columns);
+  const size_t ab = size_t(inst->num_rounds) * c * eb, mb = c * c * eb;
+  int rc = blob->alloc(2 * ab + mb);
+  if (rc) return rc;
+  char* b = (char*)blob->p;
+  HIP_TRY(hipMemcpy(b, inst->ark_c, ab, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b + ab, inst->ark_d, ab, hipMemcpyHostToDevice));
+  if (inst->mds) {
+    HIP_TRY(hipMemcpy(b + 2 * ab, inst->mds, mb, hipMemcpyHostToDevice));
+  } else {
+    std::vector<uint64_t> small, canon(c * c * (eb / 8), 0);
+    if (!builtin_mds(inst->num_columns, uint64_t(ops->generator), &small)) return ANEMOI_ERR_ARG;
+    for (size_t i = 0; i < c * c; i++) canon[i * (eb / 8)] = small[i];
+    HIP_TRY(hipMemcpy(b + 2 * ab, canon.data(), mb, hipMemcpyHostToDevice));
+    HIP_TRY(ops->mont_convert(1, b + 2 * ab, b + 2 * ab, c * c, nullptr));
+  }
+  gc->ark_c = (const uint32_t*)b;
+  gc->ark_d = (const uint32_t*)(b + ab);
+  gc->mds = (const uint32_t*)(b + 2 * ab);
+  gc->cols = inst->num_columns;
+  gc->rounds = inst->num_rounds;
+  return ANEMOI_OK;
+}
+
+// host-pointer batch over a run-time instance: constants are uploaded per device, then `launch`
+template <class LaunchFn>
+int generic_batch(const anemoi_generic_instance* inst, int device, size_t n, const void* in, size_t in_per_item,
+                  void* out, size_t out_per_item, LaunchFn launch) {
+  if (n == 0) return ANEMOI_OK;
+  return for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
+    if (count == 0) return ANEMOI_OK;
+    DeviceGuard guard;
+    HIP_TRY(hipSetDevice(dev));
+    DevBuf blob, din, dout;
+    anemoi::GenericConsts gc;
+    PermConsts pc;
+    int rc = upload_generic(inst, &blob, &gc);
+    if (!rc) rc = get_consts(inst->field, 2, &pc);  // exponent schedule of the field
+    if (!rc) rc = din.alloc(count * in_per_item);
+    if (!rc && out != in) rc = dout.alloc(count * out_per_item);
+    if (rc) return rc;
+    void* o = out != in ? dout.p : din.p;
+    HIP_TRY(hipMemcpy(din.p, (const char*)in + first * in_per_item, count * in_per_item, hipMemcpyHostToDevice));
+    HIP_TRY(launch(din.p, o, count, gc, pc));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy((char*)out + first * out_per_item, o, count * out_per_item, hipMemcpyDeviceToHost));
+    return ANEMOI_OK;
+  });
+}
+
 int merkle_levels_dev(int field, const void* d_leaves, unsigned depth, void* d_scratch, void* d_root,
                       hipStream_t s) {
   const FieldOps* ops = anemoi::field_ops(field);
@@ -307,6 +425,84 @@ int anemoi_num_rounds(int field, int width) {
   if (rc) return rc;
   const FieldOps* o = anemoi::field_ops(field);
   return width == 2 ? o->rounds21 : o->rounds43;
+}
+
+/* ---- run-time instances ---- */
+
+int anemoi_generic_mds_matrix(int field, int num_columns, uint64_t* mds, int device) {
+  const FieldOps* ops = anemoi::field_ops(field);
+  if (!ops) return ANEMOI_ERR_FIELD;
+  std::vector<uint64_t> small;
+  if (!mds || !builtin_mds(num_columns, uint64_t(ops->generator), &small)) return ANEMOI_ERR_ARG;
+  const size_t L = size_t(ops->limbs64), cnt = small.size();
+  std::vector<uint64_t> canon(cnt * L, 0);
+  for (size_t i = 0; i < cnt; i++) canon[i * L] = small[i];
+  return anemoi_to_montgomery(field, canon.data(), mds, cnt, device == ANEMOI_ALL_DEVICES ? 0 : device);
+}
+
+int anemoi_generic_permutation_batch(const anemoi_generic_instance* inst, uint64_t* states, size_t n, int device) {
+  int rc = check_generic(inst);
+  if (rc) return rc;
+  if (n && !states) return ANEMOI_ERR_ARG;
+  const size_t per = elem_bytes(inst->field) * 2 * size_t(inst->num_columns);
+  return generic_batch(inst, device, n, states, per, states, per,
+                       [&](void* i, void*, size_t cnt, anemoi::GenericConsts gc, PermConsts pc) {
+                         return anemoi::field_ops(inst->field)->generic_permutation(i, cnt, gc, pc, nullptr);
+                       });
+}
+
+int anemoi_generic_jive_compress_k_batch(const anemoi_generic_instance* inst, int k, const uint64_t* in,
+                                         uint64_t* out, size_t n, int device) {
+  int rc = check_generic(inst);
+  if (rc) return rc;
+  const int w = 2 * inst->num_columns;
+  // the reference's asserts (anemoi_4_3/hasher.rs:163-165): k <= width, k | width, k even
+  if (k < 2 || k > w || w % k != 0 || k % 2 != 0) return ANEMOI_ERR_ARG;
+  if (n && (!in || !out)) return ANEMOI_ERR_ARG;
+  if ((const void*)in == (void*)out) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(inst->field);
+  return generic_batch(inst, device, n, in, eb * w, out, eb * (w / k),
+                       [&](void* i, void* o, size_t cnt, anemoi::GenericConsts gc, PermConsts pc) {
+                         return anemoi::field_ops(inst->field)->generic_jive(i, o, cnt, k, gc, pc, nullptr);
+                       });
+}
+
+static int generic_hash(const anemoi_generic_instance* inst, int rate, int bytes, const void* src, size_t per_msg,
+                        size_t n, uint64_t* out, int device) {
+  int rc = check_generic(inst);
+  if (rc) return rc;
+  if (rate < 1 || rate >= 2 * inst->num_columns) return ANEMOI_ERR_ARG;
+  if (n && (!out || (per_msg && !src))) return ANEMOI_ERR_ARG;
+  static const uint64_t dummy[2] = {0, 0};
+  const size_t eb = elem_bytes(inst->field);
+  return generic_batch(inst, device, n, src ? src : (const void*)dummy, bytes ? per_msg : eb * per_msg, out, eb,
+                       [&](void* i, void* o, size_t cnt, anemoi::GenericConsts gc, PermConsts pc) {
+                         return anemoi::field_ops(inst->field)->generic_sponge(bytes, i, per_msg, cnt, o, rate, gc, pc,
+                                                                               nullptr);
+                       });
+}
+
+int anemoi_generic_hash_field_batch(const anemoi_generic_instance* inst, int rate, const uint64_t* elems,
+                                    size_t elems_per_msg, size_t n, uint64_t* out, int device) {
+  return generic_hash(inst, rate, 0, elems, elems_per_msg, n, out, device);
+}
+
+int anemoi_generic_hash_bytes_batch(const anemoi_generic_instance* inst, int rate, const uint8_t* msgs, size_t msg_len,
+                                    size_t n, uint64_t* out, int device) {
+  return generic_hash(inst, rate, 1, msgs, msg_len, n, out, device);
+}
+
+int anemoi_exp_alpha_batch(int field, int inverse, uint64_t* elems, size_t n, int device) {
+  if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
+  if (n && !elems) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field);
+  return host_batch(device, n, elems, eb, elems, eb, [&](void* i, void*, size_t cnt, hipStream_t s) -> int {
+    PermConsts pc;
+    int rc = get_consts(field, 2, &pc);
+    if (rc) return rc;
+    HIP_TRY(anemoi::field_ops(field)->exp_alpha(inverse ? 1 : 0, i, cnt, pc, s));
+    return ANEMOI_OK;
+  });
 }
 
 /* ---- device-pointer API ---- */

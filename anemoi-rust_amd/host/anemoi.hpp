@@ -166,6 +166,50 @@ struct Instance {
   }
 };
 
+// An instance described by the `Anemoi` trait's constants (src/traits.rs:36-76) instead of by a type:
+// what a maintainer adding e.g. an Anemoi-8-7 instance would fill in.  `mds` empty = the reference's
+// hard-coded mds_layer arm (NUM_COLUMNS <= 6, src/traits.rs:136-279).
+template <int FIELD, int LIMBS>
+struct GenericInstance {
+  using F = Felt<LIMBS>;
+  size_t num_columns, num_rounds;
+  std::vector<F> ark_c, ark_d, mds;
+
+  size_t state_width() const { return 2 * num_columns; }
+  anemoi_generic_instance raw() const {
+    if (ark_c.size() != num_columns * num_rounds || ark_d.size() != ark_c.size() ||
+        (!mds.empty() && mds.size() != num_columns * num_columns))
+      throw std::invalid_argument("GenericInstance: constant tables do not match NUM_COLUMNS / NUM_ROUNDS");
+    return anemoi_generic_instance{FIELD, int(num_columns), int(num_rounds),
+                                   ark_c.empty() ? nullptr : ark_c[0].limbs.data(),
+                                   ark_d.empty() ? nullptr : ark_d[0].limbs.data(),
+                                   mds.empty() ? nullptr : mds[0].limbs.data()};
+  }
+  void permutation_batch(std::vector<F>& states, int device = 0) const {
+    if (states.size() % state_width()) throw std::invalid_argument("permutation_batch: not a whole number of states");
+    const auto inst = raw();
+    check(anemoi_generic_permutation_batch(&inst, states.empty() ? nullptr : states[0].limbs.data(),
+                                           states.size() / state_width(), device));
+  }
+  std::vector<F> compress_k_batch(const std::vector<F>& states, size_t k, int device = 0) const {
+    if (states.size() % state_width()) throw std::invalid_argument("compress_k_batch: not a whole number of states");
+    if (k == 0 || state_width() % k) throw std::invalid_argument("compress_k: STATE_WIDTH % k != 0");
+    const size_t n = states.size() / state_width();
+    std::vector<F> out(n * (state_width() / k));
+    const auto inst = raw();
+    check(anemoi_generic_jive_compress_k_batch(&inst, int(k), n ? states[0].limbs.data() : nullptr,
+                                               n ? out[0].limbs.data() : nullptr, n, device));
+    return out;
+  }
+  Digest<FIELD, LIMBS> hash_field(const std::vector<F>& elems, size_t rate, int device = 0) const {
+    Digest<FIELD, LIMBS> d;
+    const auto inst = raw();
+    check(anemoi_generic_hash_field_batch(&inst, int(rate), elems.empty() ? nullptr : elems[0].limbs.data(), elems.size(),
+                                          1, d.elements[0].limbs.data(), device));
+    return d;
+  }
+};
+
 // the reference's 14 unit structs (src/<field>/anemoi_X_Y/mod.rs:37-38); rounds from :31
 using AnemoiBls12_381_2_1 = Instance<ANEMOI_BLS12_381, 2, 6, 21>;
 using AnemoiBls12_381_4_3 = Instance<ANEMOI_BLS12_381, 4, 6, 14>;

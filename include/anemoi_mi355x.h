@@ -132,6 +132,43 @@ int anemoi_merkle_root_arity4(int field, const uint64_t *leaves, unsigned depth4
 int anemoi_to_montgomery(int field, const uint64_t *in, uint64_t *out, size_t count, int device);
 int anemoi_from_montgomery(int field, const uint64_t *in, uint64_t *out, size_t count, int device);
 
+/* ---- instances given by their trait constants (src/traits.rs:36-76) -------------------------------
+ * The reference's `Anemoi` trait is generic over NUM_COLUMNS, NUM_ROUNDS, ARK_C, ARK_D and an optional
+ * MDS matrix, with hard-coded `mds_layer` arms for 1..6 columns and a matrix arm beyond
+ * (src/traits.rs:136-304); the shipped instances use 1 and 2 columns only.  These entry points run any
+ * such instance over one of the seven fields (ALPHA, BETA = generator, DELTA come with the field):
+ * state width = 2 * num_columns elements, laid out [x_0 .. x_{c-1}, y_0 .. y_{c-1}] like the
+ * reference's `state` slice.  All pointers are host memory; constants are Montgomery elements. */
+typedef struct anemoi_generic_instance {
+  int field;             /* field id */
+  int num_columns;       /* NUM_COLUMNS, 1 .. ANEMOI_MAX_GENERIC_COLUMNS */
+  int num_rounds;        /* NUM_ROUNDS, 1 .. 255 */
+  const uint64_t *ark_c; /* ARK_C: num_rounds * num_columns elements (round-major, src/traits.rs:116-123) */
+  const uint64_t *ark_d; /* ARK_D: same shape */
+  const uint64_t *mds;   /* MDS: num_columns^2 elements, row-major; NULL selects the reference's hard-coded
+                          * arm for num_columns <= 6 (and is an error beyond, like the reference's expect()) */
+} anemoi_generic_instance;
+#define ANEMOI_MAX_GENERIC_COLUMNS 16
+
+/* The matrix the reference's hard-coded mds_layer arm for num_columns (1..6) applies to each half of the
+ * state, as num_columns^2 row-major Montgomery elements (src/traits.rs:136-279, :307-323). */
+int anemoi_generic_mds_matrix(int field, int num_columns, uint64_t *mds, int device);
+/* Anemoi::permutation (src/traits.rs:370-378), in place: n states of 2 * num_columns elements */
+int anemoi_generic_permutation_batch(const anemoi_generic_instance *inst, uint64_t *states, size_t n, int device);
+/* Jive compress_k with the reference's argument rules (k even, k divides the state width;
+ * anemoi_4_3/hasher.rs:162-179): n states -> n x (2 * num_columns / k) elements */
+int anemoi_generic_jive_compress_k_batch(const anemoi_generic_instance *inst, int k, const uint64_t *in,
+                                         uint64_t *out, size_t n, int device);
+/* Sponge::hash_field / Sponge::hash with RATE_WIDTH = rate (1 .. 2 * num_columns - 1), digest = state[0]
+ * (anemoi_4_3/hasher.rs:19-129): n messages of elems_per_msg elements / msg_len bytes -> n digests */
+int anemoi_generic_hash_field_batch(const anemoi_generic_instance *inst, int rate, const uint64_t *elems,
+                                    size_t elems_per_msg, size_t n, uint64_t *out, int device);
+int anemoi_generic_hash_bytes_batch(const anemoi_generic_instance *inst, int rate, const uint8_t *msgs,
+                                    size_t msg_len, size_t n, uint64_t *out, int device);
+/* Element-wise x^ALPHA (exp_by_alpha, src/traits.rs:94-104; inverse = 0) or x^(1/ALPHA) (exp_by_inv_alpha,
+ * src/<f>/sbox.rs; inverse = 1), in place -- the pair the reference's test_alpha checks against each other. */
+int anemoi_exp_alpha_batch(int field, int inverse, uint64_t *elems, size_t n, int device);
+
 /* ---- device-pointer API (buffers in the current device's HBM; asynchronous on `stream`) --- */
 int anemoi_permutation_dev(int field, int width, void *d_states, size_t n, void *stream);
 int anemoi_sbox_layer_dev(int field, int width, void *d_states, size_t n, void *stream);

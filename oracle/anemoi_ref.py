@@ -197,3 +197,213 @@ class Instance:
         while len(level) > 1:
             level = [self.compress_k(level[4 * i: 4 * i + 4], 4)[0] for i in range(len(level) // 4)]
         return level[0]
+
+
+# ---- generality the reference carries but no shipped instance uses -----------------
+def mul_by_generator_chain(x, g, p):
+    """src/traits.rs:78-91, arm by arm (double / add chains; `_` arm is a real multiplication)."""
+    d = lambda v: 2 * v % p
+    if g == 2:
+        return d(x)
+    if g == 3:
+        return (d(x) + x) % p
+    if g == 5:
+        return (d(d(x)) + x) % p
+    if g == 7:
+        return (d((d(x) + x) % p) + x) % p
+    if g == 9:
+        return (d(d(d(x))) + x) % p
+    if g == 11:
+        return (d((d(d(x)) + x) % p) + x) % p
+    if g == 13:
+        return (d((d((d(x) + x) % p) + x) % p) + x) % p
+    if g == 15:
+        return (d(d(d(d(x)))) - x) % p
+    if g == 17:
+        return (d(d(d(d(x)))) + x) % p
+    return g * x % p
+
+
+def exp_by_alpha_chain(x, alpha, p):
+    """src/traits.rs:94-104, arm by arm."""
+    sq = lambda v: v * v % p
+    if alpha == 3:
+        return sq(x) * x % p
+    if alpha == 5:
+        return sq(sq(x)) * x % p
+    if alpha == 7:
+        return sq(sq(x) * x % p) * x % p
+    if alpha == 11:
+        return sq(sq(sq(x)) * x % p) * x % p
+    if alpha == 13:
+        return sq(sq(sq(x) * x % p) * x % p) * x % p
+    if alpha == 17:
+        return sq(sq(sq(sq(x)))) * x % p
+    return pow(x, alpha, p)
+
+
+def mds_internal(s, g, p):
+    """src/traits.rs:307-323 on a 3- or 4-element half state (list, in place)."""
+    G = lambda v: mul_by_generator_chain(v, g, p)
+    if len(s) == 3:
+        tmp = (s[0] + G(s[2])) % p
+        s[2] = (s[2] + s[1]) % p
+        s[2] = (s[2] + G(s[0])) % p
+        s[0] = (tmp + s[2]) % p
+        s[1] = (s[1] + tmp) % p
+    elif len(s) == 4:
+        s[0] = (s[0] + s[1]) % p
+        s[2] = (s[2] + s[3]) % p
+        s[3] = (s[3] + G(s[0])) % p
+        s[1] = G((s[1] + s[2]) % p)
+        s[0] = (s[0] + s[1]) % p
+        s[2] = (s[2] + G(s[3])) % p
+        s[1] = (s[1] + s[2]) % p
+        s[3] = (s[3] + s[0]) % p
+
+
+def mds_layer_arm(st, c, g, p, mds=None):
+    """src/traits.rs:136-304: the hard-coded arms NUM_COLUMNS = 1..6 and the generic matrix arm (`mds`
+    = row-major c x c list) -- statement by statement, in place on the 2c-element state."""
+    G = lambda v: mul_by_generator_chain(v, g, p)
+    if mds is None and c == 1:
+        st[1] = (st[1] + st[0]) % p
+        st[0] = (st[0] + st[1]) % p
+        return
+    if mds is None and c == 2:
+        st[0] = (st[0] + G(st[1])) % p
+        st[1] = (st[1] + G(st[0])) % p
+        st[3] = (st[3] + G(st[2])) % p
+        st[2] = (st[2] + G(st[3])) % p
+        st[2], st[3] = st[3], st[2]
+    elif mds is None and c in (3, 4):
+        x = st[:c]
+        mds_internal(x, g, p)
+        y = st[c:]
+        y = y[1:] + y[:1]  # rotate_left(1)
+        mds_internal(y, g, p)
+        st[:c], st[c:] = x, y
+    elif mds is None and c == 5:
+        for half in (0, 1):
+            v = st[:c] if half == 0 else st[c + 1:] + st[c:c + 1]
+            tot = sum(v) % p
+            out = [(tot + v[(i + 3) % 5] + 2 * (v[(i + 2) % 5] + v[(i + 3) % 5] + 2 * v[(i + 4) % 5])) % p
+                   for i in range(5)]
+            st[half * c:(half + 1) * c] = out
+    elif mds is None and c == 6:
+        for half in (0, 1):
+            v = st[:c] if half == 0 else st[c + 1:] + st[c:c + 1]
+            tot = sum(v) % p
+            out = [(tot + v[(i + 3) % 6] + v[(i + 5) % 6]
+                    + 2 * (v[(i + 2) % 6] + v[(i + 3) % 6] + 2 * (v[(i + 4) % 6] + v[(i + 5) % 6]))) % p
+                   for i in range(6)]
+            st[half * c:(half + 1) * c] = out
+    else:
+        if mds is None:
+            raise ValueError("NO MDS matrix specified for this instance.")  # the reference's expect()
+        x, y = st[:c], st[c + 1:] + st[c:c + 1]
+        rx = [sum(mds[i * c + j] * x[j] for j in range(c)) % p for i in range(c)]
+        ry = [sum(mds[i * c + j] * y[j] for j in range(c)) % p for i in range(c)]
+        for i in range(c):
+            st[c + i] = (rx[i] + ry[i]) % p
+        for i in range(c):
+            st[i] = (rx[i] + st[c + i]) % p
+        return
+    # PHT layer of the hard-coded arms 2..6
+    for i in range(c):
+        st[c + i] = (st[c + i] + st[i]) % p
+    for i in range(c):
+        st[i] = (st[i] + st[c + i]) % p
+
+
+def builtin_mds_matrix(c, g, p):
+    """The c x c matrix (row-major canonical ints) that the hard-coded arm for NUM_COLUMNS = c applies
+    to each half of the state -- read off by feeding unit vectors through the arm's x half."""
+    cols = []
+    for j in range(c):
+        st = [0] * (2 * c)
+        st[j] = 1
+        if c == 1:
+            out = [1]
+        elif c == 2:
+            x = st[:2]
+            x[0] = (x[0] + g * x[1]) % p
+            x[1] = (x[1] + g * x[0]) % p
+            out = x
+        elif c in (3, 4):
+            x = st[:c]
+            mds_internal(x, g, p)
+            out = x
+        else:
+            full = list(st)
+            mds_layer_arm(full, c, g, p)
+            # undo the PHT step for the x half: x_final = x' + y_final, y_final = y' + x' and y' = 0 here
+            out = [full[c + i] for i in range(c)]
+        cols.append(out)
+    return [cols[j][i] for i in range(c) for j in range(c)]
+
+
+class GenericInstance:
+    """An Anemoi instance given by its trait constants (src/traits.rs:36-76): field, NUM_COLUMNS,
+    NUM_ROUNDS, ARK_C, ARK_D and optionally an MDS matrix.  mds=None selects the reference's
+    hard-coded `mds_layer` arm (NUM_COLUMNS <= 6)."""
+
+    def __init__(self, field, cols, rounds, ark_c, ark_d, mds=None, params=None):
+        base = Instance(field, 2, params)
+        self.base, self.field = base, field
+        self.p, self.g, self.delta = base.p, base.g, base.delta
+        self.alpha, self.inv_alpha = base.alpha, base.inv_alpha
+        self.cols, self.width, self.rounds = cols, 2 * cols, rounds
+        self.C, self.D = list(ark_c), list(ark_d)
+        assert len(self.C) == len(self.D) == cols * rounds
+        self.mds = None if mds is None else list(mds)
+        self.limbs, self.nbytes = base.limbs, base.nbytes
+        self.to_mont, self.from_mont = base.to_mont, base.from_mont
+
+    def mds_layer(self, st):
+        mds_layer_arm(st, self.cols, self.g, self.p, self.mds)
+
+    def sbox_layer(self, st):
+        c, p = self.cols, self.p
+        for i in range(c):
+            x, y = st[i], st[c + i]
+            x = (x - mul_by_generator_chain(y * y % p, self.g, p)) % p
+            y = (y - pow(x, self.inv_alpha, p)) % p
+            x = (x + mul_by_generator_chain(y * y % p, self.g, p) + self.delta) % p
+            st[i], st[c + i] = x, y
+
+    def permutation(self, st):
+        assert len(st) == self.width
+        c, p = self.cols, self.p
+        for r in range(self.rounds):
+            for i in range(c):
+                st[i] = (st[i] + self.C[r * c + i]) % p
+                st[c + i] = (st[c + i] + self.D[r * c + i]) % p
+            self.mds_layer(st)
+            self.sbox_layer(st)
+        self.mds_layer(st)
+        return st
+
+    def compress_k(self, elems, k):
+        """Jive with the reference's argument rules (anemoi_4_3/hasher.rs:162-179)."""
+        w = self.width
+        assert len(elems) == w and k <= w and w % k == 0 and k % 2 == 0
+        st = self.permutation(list(elems))
+        c = w // k
+        return [sum(elems[i + c * j] + st[i + c * j] for j in range(k)) % self.p for i in range(c)]
+
+    def hash_field(self, elems, rate):
+        """the sponge of anemoi_4_3/hasher.rs:93-129 with RATE_WIDTH = rate"""
+        st, i = [0] * self.width, 0
+        for e in elems:
+            st[i] = (st[i] + e) % self.p
+            i += 1
+            if i == rate:
+                self.permutation(st)
+                i = 0
+        sigma = 1 if len(elems) % rate == 0 else 0
+        st[self.width - 1] = (st[self.width - 1] + sigma) % self.p
+        if sigma == 0:
+            st[i] = (st[i] + 1) % self.p
+            self.permutation(st)
+        return st[0]

@@ -4,6 +4,7 @@
 //   test_anemoi_hash_bytes  (hash on the 4 structured inputs packed as full chunks)
 //   test_anemoi_jive        (compress, compress_k(.,2), merge on 2-1, compress_k(.,4) on 4-3,
 //                            and the assert! on a wrong k / wrong length)
+// plus the run-time instances of tests/golden/generic.json through GenericInstance (kind "generic").
 // Vectors come from tests/golden/kats.json, flattened by tests/test_cpp_host.py into a text file:
 //   <field_id> <width> <kind> <n_in> <n_out> <decimal>...      (kind hash_bytes: one hex string as input)
 #include <cstdio>
@@ -80,6 +81,30 @@ static void run_line(const std::string& kind, const std::vector<std::string>& in
   }
 }
 
+// a run-time instance (tests/golden/generic.json): in = rounds, has_mds, ARK_C, ARK_D, [MDS], state
+template <int FIELD, int L>
+static void run_generic(size_t cols, const std::vector<std::string>& in, const std::vector<std::string>& out) {
+  using I = Instance<FIELD, 2, L, 1>;  // only for from_canonical
+  auto felt = [](const std::string& d) { return I::from_canonical(parse_dec<L>(d)); };
+  GenericInstance<FIELD, L> g;
+  g.num_columns = cols;
+  g.num_rounds = size_t(std::stoul(in[0]));
+  const bool has_mds = in[1] == "1";
+  size_t pos = 2;
+  for (size_t i = 0; i < cols * g.num_rounds; i++) g.ark_c.push_back(felt(in[pos++]));
+  for (size_t i = 0; i < cols * g.num_rounds; i++) g.ark_d.push_back(felt(in[pos++]));
+  if (has_mds)
+    for (size_t i = 0; i < cols * cols; i++) g.mds.push_back(felt(in[pos++]));
+  std::vector<Felt<L>> st, expected;
+  for (size_t i = 0; i < 2 * cols; i++) st.push_back(felt(in[pos++]));
+  for (auto& o : out) expected.push_back(felt(o));
+  g.permutation_batch(st);
+  EXPECT(st == expected, "generic permutation");
+  bool threw = false;
+  try { g.compress_k_batch(expected, 2 * cols + 2); } catch (const std::invalid_argument&) { threw = true; }
+  EXPECT(threw, "compress_k with k > STATE_WIDTH must be rejected");
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   std::ifstream f(argv[1]);
@@ -94,6 +119,11 @@ int main(int argc, char** argv) {
     for (auto& s : in) ss >> s;
     for (auto& s : out) ss >> s;
     lines++;
+    if (kind == "generic") {
+#define GCASE(FID, L) if (field == FID) run_generic<FID, L>(size_t(width), in, out);
+      GCASE(0, 6) GCASE(1, 6) GCASE(2, 4) GCASE(3, 4) GCASE(4, 4) GCASE(5, 4) GCASE(6, 4)
+      continue;
+    }
 #define CASE(FID, W, T) if (field == FID && width == W) run_line<T>(kind, in, out);
     CASE(0, 2, AnemoiBls12_381_2_1) CASE(0, 4, AnemoiBls12_381_4_3) CASE(1, 2, AnemoiBls12_377_2_1)
     CASE(1, 4, AnemoiBls12_377_4_3) CASE(2, 2, AnemoiBn254_2_1) CASE(2, 4, AnemoiBn254_4_3)

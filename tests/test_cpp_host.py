@@ -38,6 +38,14 @@ def test_reference_style_cpp_tests(tmp_path, kats):
         if width == 4:
             for a, b in zip(k["jive_k4"]["in"], k["jive_k4"]["out"]):
                 lines.append("%d %d jive_k4 %d %d %s %s" % (fid, width, len(a), len(b), " ".join(a), " ".join(b)))
+    # run-time instances (tests/golden/generic.json): `width` column = NUM_COLUMNS, inputs =
+    # rounds, has_mds, ARK_C, ARK_D, [MDS], state; outputs = permutation(state)
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "generic.json")) as f:
+        for v in json.load(f):
+            ins = [str(v["num_rounds"]), "1" if v["mds"] else "0"] + v["ark_c"] + v["ark_d"] + (v["mds"] or []) + v["state"]
+            lines.append("%d %d generic %d %d %s %s" % (FIELD_IDS.index(v["field"]), v["num_columns"], len(ins),
+                                                        len(v["permutation"]), " ".join(ins), " ".join(v["permutation"])))
     path = tmp_path / "kats.txt"
     path.write_text("\n".join(lines) + "\n")
     out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=600)

@@ -117,3 +117,75 @@ def test_c_oracle_matches_minted_goldens(oracle):
         fid = FIELD_IDS.index(v["field"])
         got = oracle.merkle_root(fid, oracle.ints_to_mont(fid, ints(v["leaves"])), v["depth"])
         assert oracle.mont_to_ints(fid, got) == [int(v["root"])]
+
+
+# ---- generality beyond the shipped instances ---------------------------------------
+
+@pytest.mark.parametrize("field", FIELD_IDS)
+def test_mds_arms_agree_with_their_matrices(field):
+    """each hard-coded mds_layer arm (src/traits.rs:136-279) == the matrix arm (:281-304) fed with the
+    matrix read off the arm -- the form the GPU kernels evaluate"""
+    import anemoi_ref as R
+    b = R.Instance(field, 2)
+    rng = random.Random(FIELD_IDS.index(field))
+    for c in range(1, 7):
+        M = R.builtin_mds_matrix(c, b.g, b.p)
+        for _ in range(5):
+            st = [rng.randrange(b.p) for _ in range(2 * c)]
+            arm, mat = list(st), list(st)
+            R.mds_layer_arm(arm, c, b.g, b.p)
+            R.mds_layer_arm(mat, c, b.g, b.p, M)
+            assert arm == mat, (field, c)
+    # the 3-column matrix is the Anemoi paper's M_3 = [[g+1, 1, g+1], [1, 1, g], [g, 1, 1]]
+    g = b.g
+    assert R.builtin_mds_matrix(3, g, b.p) == [g + 1, 1, g + 1, 1, 1, g, g, 1, 1]
+    with pytest.raises(ValueError):
+        R.mds_layer_arm([0] * 14, 7, b.g, b.p)
+
+
+@pytest.mark.parametrize("field,width", INSTANCES)
+def test_generic_oracle_reproduces_reference_kats(kats, field, width):
+    """GenericInstance fed with the shipped constants must be the shipped instance: pins the generic
+    restatement (ark / matrix arm / sponge / Jive with run-time sizes) on the reference's own vectors"""
+    import anemoi_ref as R
+    I, k = R.Instance(field, width), kats[inst_key(field, width)]
+    for M in (None, R.builtin_mds_matrix(width // 2, I.g, I.p)):
+        G = R.GenericInstance(field, width // 2, I.rounds, I.C, I.D, M)
+        for a, b in zip(k["hash_field"]["in"], k["hash_field"]["out"]):
+            assert G.hash_field([int(x) for x in a], I.rate) == int(b)
+        for a, b in zip(k["jive"]["in"], k["jive"]["out"]):
+            assert G.compress_k([int(x) for x in a], 2) == [int(x) for x in b]
+        if width == 4:
+            for a, b in zip(k["jive_k4"]["in"], k["jive_k4"]["out"]):
+                assert G.compress_k([int(x) for x in a], 4) == [int(x) for x in b]
+
+
+@pytest.mark.parametrize("field", FIELD_IDS)
+def test_exp_by_alpha_chain(field):
+    """src/traits.rs:94-104 and the reference's test_alpha (chain == pow, inverse round trip)"""
+    import anemoi_ref as R
+    b = R.Instance(field, 2)
+    rng = random.Random(3)
+    for x in [0, 1, b.p - 1] + [rng.randrange(b.p) for _ in range(5)]:
+        up = R.exp_by_alpha_chain(x, b.alpha, b.p)
+        assert up == pow(x, b.alpha, b.p)
+        assert pow(up, b.inv_alpha, b.p) == x
+    for g in (2, 3, 5, 7, 9, 11, 15, 17, 22):
+        assert R.mul_by_generator_chain(12345, g, b.p) == 12345 * g % b.p
+    # upstream defect, restated literally: the arm for GROUP_GENERATOR = 13 (src/traits.rs:87) computes
+    # ((2x + x) 2 + x) 2 + x = 15 x.  No shipped field has generator 13, so nothing on the path sees it.
+    assert R.mul_by_generator_chain(12345, 13, b.p) == 12345 * 15 % b.p
+
+
+def test_generic_golden_file_matches_oracle():
+    """tests/golden/generic.json is what oracle/anemoi_ref.py computes today (regenerable fixture)"""
+    import json
+    import os
+    import anemoi_ref as R
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generic.json")) as f:
+        vecs = json.load(f)
+    for v in vecs[::4]:
+        G = R.GenericInstance(v["field"], v["num_columns"], v["num_rounds"], [int(x) for x in v["ark_c"]],
+                              [int(x) for x in v["ark_d"]], None if v["mds"] is None else [int(x) for x in v["mds"]])
+        assert G.permutation([int(x) for x in v["state"]]) == [int(x) for x in v["permutation"]]
+        assert G.hash_field([int(x) for x in v["message"]], v["rate"]) == int(v["hash_field"])
