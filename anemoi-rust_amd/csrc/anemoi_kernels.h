@@ -473,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
   constexpr int NL = C::NL, NABI = C::NABI, R = F::kRounds21, E = 16;
   __shared__ uint32_t tab[E * kBlock];
   const uint32_t lane = threadIdx.x;
-  const uint32_t pl = C::konst(F::P29), kpl = C::konst(F::KP29), delta = C::konst(F::Delta29);
+  const uint32_t pl = C::konst(C::L::P), kpl = C::konst(C::L::KP), delta = C::konst(C::L::Delta);
   for (size_t item = blockIdx.x; item < n; item += gridDim.x) {
     const uint32_t w0 = lane < NABI ? in[(item * 2 + 0) * NABI + lane] : 0u;
     const uint32_t w1 = lane < NABI ? in[(item * 2 + 1) * NABI + lane] : 0u;
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
 #pragma nounroll
     for (int r = 0; r <= R; r++) {
       if (r < R) {  // ark_layer (src/traits.rs:111-125)
-        x = C::add(x, lane < NL ? pc.ark_c[r * NL + lane] : 0u);
-        y = C::add(y, lane < NL ? pc.ark_d[r * NL + lane] : 0u);
+        x = C::add(x, lane < NL ? pc.coop_c[r * NL + lane] : 0u);
+        y = C::add(y, lane < NL ? pc.coop_d[r * NL + lane] : 0u);
       }
       // mds_layer, NUM_COLUMNS = 1 (src/traits.rs:136-142), then back below 2p
       y = C::add(y, x);
@@ -554,7 +554,8 @@ namespace anemoi {
 // ---- launchers (one set per field translation unit) ------------------------------------------------
 
 struct HostConsts {  // what the context uploads for one (field, width)
-  std::vector<uint32_t> ark_c, ark_d;
+  std::vector<uint32_t> ark_c, ark_d;    // lane-private limb layout (F::Lane)
+  std::vector<uint32_t> coop_c, coop_d;  // Anemoi-2-1 constants in the cooperative kernels' layout (F::Coop)
   std::vector<uint8_t> sched, sched5;
   int steps, first, steps5, first5;
 };
@@ -596,6 +597,9 @@ struct Launch {
     const int cnt = (width == 2 ? F::kRounds21 : 2 * F::kRounds43) * A::NL;
     hc->ark_c.assign(c, c + cnt);
     hc->ark_d.assign(d, d + cnt);
+    using CL = typename F::Coop;
+    hc->coop_c.assign(CL::ArkC_21, CL::ArkC_21 + F::kRounds21 * CL::NL);
+    hc->coop_d.assign(CL::ArkD_21, CL::ArkD_21 + F::kRounds21 * CL::NL);
     static_assert(WIN >= 2 && WIN <= 5, "schedules are generated for 2..5-bit windows");
     hc->sched5.assign(F::kW5Sched, F::kW5Sched + 2 * F::kW5Steps);
     hc->steps5 = F::kW5Steps, hc->first5 = F::kW5First;
@@ -629,7 +633,7 @@ struct Launch {
 
   static hipError_t jive(int width, int k, const void* in, void* out, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (width == 2 && n <= coop_max_items(F::NL29)) {  // latency path: one item per wavefront
+    if (width == 2 && n <= coop_max_items(F::Coop::NL)) {  // latency path: one item per wavefront
       const unsigned g = n < 65536 ? unsigned(n) : 65536u;  // the kernel strides over items
       k_jive2_coop<FIELD><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();

@@ -73,6 +73,9 @@ struct PermConsts {
   const uint8_t* sched5;
   int steps5;
   int first5;
+  // Anemoi-2-1 round constants in the cooperative kernels' limb layout (F::Coop)
+  const uint32_t* coop_c;
+  const uint32_t* coop_d;
 };
 
 // r = x^INV_ALPHA.  WIN-bit sliding window over odd powers; table entry 0 is x itself (registers).

@@ -65,22 +65,29 @@ int get_consts(int field, int width, PermConsts* out) {
   if (!c.ready[field][wi]) {
     anemoi::HostConsts hc;
     anemoi::field_ops(field)->host_consts(width, &hc);
-    const size_t ab = hc.ark_c.size() * sizeof(uint32_t), sb = hc.sched.size(), sb5 = hc.sched5.size();
+    const size_t ab = hc.ark_c.size() * sizeof(uint32_t), sb = hc.sched.size(), sb5 = (hc.sched5.size() + 3) / 4 * 4;
+    const size_t cb = hc.coop_c.size() * sizeof(uint32_t);
     char* blob = nullptr;
-    HIP_TRY(hipMalloc((void**)&blob, 2 * ab + sb + sb5));
+    static_assert(sizeof(uint32_t) == 4, "");
+    const size_t sbp = (sb + 3) / 4 * 4;  // keep the 32-bit tables behind the byte schedules aligned
+    HIP_TRY(hipMalloc((void**)&blob, 2 * ab + sbp + sb5 + 2 * cb));
     HIP_TRY(hipMemcpy(blob, hc.ark_c.data(), ab, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(blob + ab, hc.ark_d.data(), ab, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(blob + 2 * ab, hc.sched.data(), sb, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(blob + 2 * ab + sb, hc.sched5.data(), sb5, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(blob + 2 * ab + sbp, hc.sched5.data(), hc.sched5.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(blob + 2 * ab + sbp + sb5, hc.coop_c.data(), cb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(blob + 2 * ab + sbp + sb5 + cb, hc.coop_d.data(), cb, hipMemcpyHostToDevice));
     PermConsts pc;
     pc.ark_c = (const uint32_t*)blob;
     pc.ark_d = (const uint32_t*)(blob + ab);
     pc.sched = (const uint8_t*)(blob + 2 * ab);
     pc.steps = hc.steps;
     pc.first = hc.first;
-    pc.sched5 = (const uint8_t*)(blob + 2 * ab + sb);
+    pc.sched5 = (const uint8_t*)(blob + 2 * ab + sbp);
     pc.steps5 = hc.steps5;
     pc.first5 = hc.first5;
+    pc.coop_c = (const uint32_t*)(blob + 2 * ab + sbp + sb5);
+    pc.coop_d = (const uint32_t*)(blob + 2 * ab + sbp + sb5 + cb);
     c.pc[field][wi] = pc;
     c.ready[field][wi] = true;
   }

@@ -27,10 +27,13 @@ namespace anemoi {
 
 template <class F>
 struct Coop29 {
-  static constexpr int NL = F::NL29;
+  using L = typename F::Coop;  // always the 29-bit layout: the systolic scan below sums a whole
+                               // column (2 NL products) in one 64-bit lane accumulator
+  static_assert(L::W == 29, "column sums of 2 NL limb products must fit 64 bits");
+  static constexpr int NL = L::NL;
   static constexpr int NABI = F::N;
   static constexpr uint32_t MASK = (1u << 29) - 1;
-  static constexpr bool kTight = F::kH29 < 4096.0;
+  static constexpr bool kTight = L::kTight;
 
   // DPP within row 0 (NL <= 14 < 16 lanes): out-of-range sources read as 0 (bound_ctrl)
   __device__ static __forceinline__ uint32_t from_next(uint32_t v) {  // lane j <- lane j+1
@@ -80,7 +83,7 @@ struct Coop29 {
       const uint32_t ai = __builtin_amdgcn_readlane(a, i);
       t += (uint64_t)ai * b;
       const uint32_t t0 = __builtin_amdgcn_readlane((uint32_t)t, 0);
-      const uint32_t m = (t0 * F::kN0Inv29) & MASK;
+      const uint32_t m = (t0 * L::kN0Inv) & MASK;
       t += (uint64_t)m * pl;
       // lane 0's column is now 0 mod 2^29 and retires: its upper bits are the carry into the next
       // column.  Every column sum stays < 2^63, so shifting by 63 yields 0 in all other lanes:
@@ -100,11 +103,11 @@ struct Coop29 {
 
   // g * x (mul_by_generator, src/traits.rs:78-91)
   __device__ static __forceinline__ uint32_t mul_g(uint32_t x, uint32_t pl) {
-    if constexpr (kTight) return mul(x, konst(F::GMont29), pl);
+    if constexpr (kTight) return mul(x, konst(L::GMont), pl);
     return settle_columns((uint64_t)x * (uint32_t)F::kG);
   }
 
-  __device__ static __forceinline__ uint32_t settle(uint32_t x, uint32_t pl) { return mul(x, konst(F::One29), pl); }
+  __device__ static __forceinline__ uint32_t settle(uint32_t x, uint32_t pl) { return mul(x, konst(L::One), pl); }
 
   // x < 2p -> x mod p, exact limbs
   __device__ static __forceinline__ uint32_t canonical(uint32_t x, uint32_t pl) {
@@ -135,10 +138,10 @@ struct Coop29 {
     return lane() < NABI ? v : 0u;
   }
   __device__ static __forceinline__ uint32_t from_abi(uint32_t w, uint32_t pl) {
-    return mul(words_to_limbs(w), konst(F::In29), pl);
+    return mul(words_to_limbs(w), konst(L::In), pl);
   }
   __device__ static __forceinline__ uint32_t to_abi(uint32_t x, uint32_t pl) {
-    return limbs_to_words(canonical(mul(x, konst(F::Out29), pl), pl));
+    return limbs_to_words(canonical(mul(x, konst(L::Out), pl), pl));
   }
 };
 

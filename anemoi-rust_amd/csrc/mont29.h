@@ -31,12 +31,13 @@
 
 namespace anemoi {
 
-template <class F>
+template <class F, class L = typename F::Lane>
 struct Arith29 {
-  static constexpr int NL = F::NL29;   // limbs held in VGPRs
+  static constexpr int W = L::W;       // bits per limb: 29, or 30 for the 381/377-bit fields (see below)
+  static constexpr int NL = L::NL;     // limbs held in VGPRs
   static constexpr int NABI = F::N;    // 32-bit words of an ABI element
   static constexpr int NQ = (NL + 3) / 4;  // uint4 slots of one LDS table entry
-  static constexpr uint32_t MASK = (1u << 29) - 1;
+  static constexpr uint32_t MASK = (1u << W) - 1;
   static constexpr bool kLoose = true;  // values between reductions may exceed p (see settle())
 
   struct Fe {
@@ -47,7 +48,7 @@ struct Arith29 {
   __device__ static __forceinline__ void norm(Fe& r) {
 #pragma unroll
     for (int i = 0; i < NL - 1; i++) {
-      r.l[i + 1] += r.l[i] >> 29;
+      r.l[i + 1] += r.l[i] >> W;
       r.l[i] &= MASK;
     }
   }
@@ -65,7 +66,7 @@ struct Arith29 {
   __device__ static __forceinline__ void mul(Fe& r, const Fe& a, const Fe& b) {
 #if ANEMOI_ASM_MUL
     Fe t = a;
-    AsmMont29<F::kId>::mul(t.l, b.l);
+    AsmMont<F::kId, W>::mul(t.l, b.l);
     r = t;
     return;
 #endif
@@ -89,7 +90,7 @@ struct Arith29 {
   __device__ static __forceinline__ void sqr(Fe& r, const Fe& a) {
 #if ANEMOI_ASM_MUL
     Fe t = a;
-    AsmMont29<F::kId>::sqr(t.l);
+    AsmMont<F::kId, W>::sqr(t.l);
     r = t;
     return;
 #endif
@@ -117,16 +118,30 @@ struct Arith29 {
     const int j0 = k < NL ? 0 : k - NL + 1, j1 = k < NL ? k - 1 : NL - 1;  // m_j p_{k-j}, j in [j0, j1]
     uint64_t early = x;
 #pragma unroll
-    for (int j = j0; j < j1; j++) early += (uint64_t)m[j] * F::P29[k - j];
+    for (int j = j0; j < j1; j++) early += (uint64_t)m[j] * L::P[k - j];
+    if constexpr (W >= 30) {
+      // 30-bit limbs: a column (26 products < 2^60 each) no longer fits 64 bits -- the generated
+      // assembly splits the heavy columns; this C++ form simply carries 128 bits
+      unsigned __int128 wide = (unsigned __int128)acc + early;
+      if (j1 >= j0) wide += (uint64_t)m[j1] * L::P[k - j1];
+      if (k < NL) {
+        m[k] = ((uint32_t)wide * L::kN0Inv) & MASK;
+        wide += (uint64_t)m[k] * L::P[0];
+      } else {
+        out[k - NL] = (uint32_t)wide & MASK;
+      }
+      acc = (uint64_t)(wide >> W);
+      return;
+    }
     acc += early;
-    if (j1 >= j0) acc += (uint64_t)m[j1] * F::P29[k - j1];
+    if (j1 >= j0) acc += (uint64_t)m[j1] * L::P[k - j1];
     if (k < NL) {
-      m[k] = ((uint32_t)acc * F::kN0Inv29) & MASK;
-      acc += (uint64_t)m[k] * F::P29[0];
+      m[k] = ((uint32_t)acc * L::kN0Inv) & MASK;
+      acc += (uint64_t)m[k] * L::P[0];
     } else {
       out[k - NL] = (uint32_t)acc & MASK;
     }
-    acc >>= 29;
+    acc >>= W;
   }
 
   // r = a + b (no reduction; the caller keeps values < 2^12 p, see anemoi_perm.h)
@@ -147,20 +162,20 @@ struct Arith29 {
   // limb goes negative
   __device__ static __forceinline__ void sub(Fe& r, const Fe& a, const Fe& b) {
 #pragma unroll
-    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + F::KP29[i] - b.l[i];
+    for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + L::KP[i] - b.l[i];
     norm(r);
   }
 
   // Fields with little headroom (R'/p < 2^12: the 254/255-bit ones on 9 limbs) keep every value
   // below ~33 p: there g*x is a Montgomery product by g*R' (result < 2p) and subtraction pads with 4p.
-  static constexpr bool kTight = F::kH29 < 4096.0;
+  static constexpr bool kTight = L::kTight;
 
   // r = g * x for the small generator g (mul_by_generator, src/traits.rs:78-91)
   __device__ static __forceinline__ void mul_g(Fe& r, const Fe& x) {
     if constexpr (kTight) {
       Fe g;
 #pragma unroll
-      for (int i = 0; i < NL; i++) g.l[i] = F::GMont29[i];
+      for (int i = 0; i < NL; i++) g.l[i] = L::GMont[i];
       mul(r, x, g);
     } else {
       uint64_t acc = 0;
@@ -168,7 +183,7 @@ struct Arith29 {
       for (int i = 0; i < NL; i++) {
         acc += (uint64_t)x.l[i] * (uint32_t)F::kG;
         r.l[i] = (uint32_t)acc & MASK;
-        acc >>= 29;
+        acc >>= W;
       }
     }
   }
@@ -177,19 +192,19 @@ struct Arith29 {
   __device__ static __forceinline__ void settle(Fe& x) {
     Fe one;
 #pragma unroll
-    for (int i = 0; i < NL; i++) one.l[i] = F::One29[i];
+    for (int i = 0; i < NL; i++) one.l[i] = L::One[i];
     mul(x, x, one);
   }
 
   __device__ static __forceinline__ void set_one(Fe& x) {
 #pragma unroll
-    for (int i = 0; i < NL; i++) x.l[i] = F::One29[i];
+    for (int i = 0; i < NL; i++) x.l[i] = L::One[i];
   }
   __device__ static __forceinline__ void set_zero(Fe& x) {
 #pragma unroll
     for (int i = 0; i < NL; i++) x.l[i] = 0;
   }
-  __device__ static __forceinline__ void add_delta(Fe& r, const Fe& a) { add_k(r, a, F::Delta29); }
+  __device__ static __forceinline__ void add_delta(Fe& r, const Fe& a) { add_k(r, a, L::Delta); }
 
   // x < 2p (normalised) -> x mod p
   __device__ static __forceinline__ void canonical(Fe& x) {
@@ -197,7 +212,7 @@ struct Arith29 {
     uint32_t borrow = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-      uint32_t t = x.l[i] - F::P29[i] - borrow;
+      uint32_t t = x.l[i] - L::P[i] - borrow;
       borrow = t >> 31;
       d[i] = t & MASK;
     }
@@ -210,7 +225,7 @@ struct Arith29 {
   __device__ static __forceinline__ void repack_in(Fe& r, const uint32_t (&w)[NABI]) {
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-      const int bit = 29 * i, lo = bit >> 5, sh = bit & 31;
+      const int bit = W * i, lo = bit >> 5, sh = bit & 31;
       const uint32_t wl = lo < NABI ? w[lo] : 0u;
       const uint32_t wh = lo + 1 < NABI ? w[lo + 1] : 0u;
       const uint32_t v = sh == 0 ? wl : ((wl >> sh) | (wh << (32 - sh)));
@@ -221,10 +236,10 @@ struct Arith29 {
   __device__ static __forceinline__ void repack_out(uint32_t (&w)[NABI], const Fe& a) {
 #pragma unroll
     for (int j = 0; j < NABI; j++) {
-      const int bit = 32 * j, i0 = bit / 29, off = bit - 29 * i0;
-      uint32_t v = a.l[i0] >> off;                                  // 29 - off bits
-      if (i0 + 1 < NL) v |= a.l[i0 + 1] << (29 - off);              // next 29 bits
-      if (i0 + 2 < NL && 58 - off < 32) v |= a.l[i0 + 2] << (58 - off);
+      const int bit = 32 * j, i0 = bit / W, off = bit - W * i0;
+      uint32_t v = a.l[i0] >> off;                                  // W - off bits
+      if (i0 + 1 < NL) v |= a.l[i0 + 1] << (W - off);               // next W bits
+      if (i0 + 2 < NL && 2 * W - off < 32) v |= a.l[i0 + 2] << (2 * W - off);
       w[j] = v;
     }
   }
@@ -234,14 +249,14 @@ struct Arith29 {
     Fe k;
     repack_in(r, w);
 #pragma unroll
-    for (int i = 0; i < NL; i++) k.l[i] = F::In29[i];
+    for (int i = 0; i < NL; i++) k.l[i] = L::In[i];
     mul(r, r, k);
   }
   // internal (any value < 2^12 p) -> canonical ABI element
   __device__ static __forceinline__ void to_abi(uint32_t (&w)[NABI], const Fe& a) {
     Fe k, t;
 #pragma unroll
-    for (int i = 0; i < NL; i++) k.l[i] = F::Out29[i];
+    for (int i = 0; i < NL; i++) k.l[i] = L::Out[i];
     mul(t, a, k);
     canonical(t);
     repack_out(w, t);
@@ -251,7 +266,7 @@ struct Arith29 {
     Fe k;
     repack_in(r, w);
 #pragma unroll
-    for (int i = 0; i < NL; i++) k.l[i] = F::RR29[i];
+    for (int i = 0; i < NL; i++) k.l[i] = L::RR[i];
     mul(r, r, k);
   }
 
@@ -284,7 +299,7 @@ struct Arith29 {
   }
 
   static const uint32_t* host_ark(int width, bool d) {
-    return width == 2 ? (d ? F::ArkD29_21 : F::ArkC29_21) : (d ? F::ArkD29_43 : F::ArkC29_43);
+    return width == 2 ? (d ? L::ArkD_21 : L::ArkC_21) : (d ? L::ArkD_43 : L::ArkC_43);
   }
 };
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Generate anemoi-rust_amd/csrc/mont29_asm_gen.h: the lane-private 29-bit-limb Montgomery
-squaring and multiplication of mont29.h as hand-scheduled gfx950 assembly, one `asm volatile`
-statement per product.
+"""Generate anemoi-rust_amd/csrc/mont29_asm_gen.h: the lane-private unsaturated-limb Montgomery
+squaring and multiplication of mont29.h (29-bit limbs; also 30-bit limbs for the 381/377-bit fields)
+as hand-scheduled gfx950 assembly, one `asm volatile` statement per product.
 
 Why: hipcc reassociates the C++ product scanning of mont29.h into an operand-scanning schedule that
 needs one extra 64-bit add per column and ~30 register moves per multiplication (412 / 537
@@ -14,7 +14,7 @@ Form (NL limbs, column k of the 2 NL - 1 columns, accumulator ACC = 64-bit VGPR 
     ACC += sum m_j * p_{k-j}          v_mad_u64_u32 with p as SGPR operand
     k <  NL:  m_k = (ACC.lo * n0inv) & MASK ; ACC += m_k * p_0
     k >= NL:  out_{k-NL} = ACC.lo & MASK      (written over a_{k-NL}, dead by then)
-    ACC >>= 29
+    ACC >>= W          (+ the parked upper part of a split column, see class Column)
 No hazards need padding: only VALU -> VALU register dependences (interlocked), VCC is written (the
 unused carry-out of v_mad_u64_u32) but never read.
 
@@ -29,100 +29,149 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELD_IDS = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
-W = 29
-MASK = (1 << W) - 1
 TMP_BASE = int(os.environ.get("ANEMOI_ASM_TMP_BASE", "100"))  # clobbered VGPRs start here (even: the 64-bit accumulator is 2-aligned)
 SGPR_BASE = 60      # clobbered SGPRs of the multiplication
+CAP = 1 << 64
 
 
-def field_consts(p):
+def field_consts(p, W):
     nl = -(-(p.bit_length() + 6) // W)
-    limbs = [(p >> (W * i)) & MASK for i in range(nl)]
+    mask = (1 << W) - 1
+    limbs = [(p >> (W * i)) & mask for i in range(nl)]
     n0inv = (-pow(p, -1, 1 << W)) % (1 << W)
     return nl, limbs, n0inv
 
 
-def gen_sqr(nl, plimbs, n0inv):
+class Column:
+    """Emits the multiply-accumulates of the product columns while tracking a worst-case bound of the
+    64-bit accumulator (input limbs < 2^W, reduction digits < 2^W, the actual limbs of p).  With 29-bit
+    limbs every column fits.  With 30-bit limbs (13 limbs for 381/377 bits) the five middle columns do
+    not: there the accumulator is split once -- its upper part parked in T, the low W bits kept (they
+    are all that the reduction digit and the output limb look at) -- and T is added back after the
+    column's shift."""
+
+    def __init__(self, out, W, acc, treg):
+        self.out, self.W, self.acc, self.treg = out, W, acc, treg
+        self.ACC = "v[%d:%d]" % (acc, acc + 1)
+        self.T = "v[%d:%d]" % (treg, treg + 1)
+        self.bound = 0          # upper bound of ACC
+        self.tbound = None      # upper bound of T while a split is pending
+        self.splits = 0
+
+    def mad(self, a, b, amax, bmax):
+        term = amax * bmax
+        if self.bound + term >= CAP:
+            assert self.tbound is None, "a column needs more than one split"
+            self.out.append("v_lshrrev_b64 %s, %d, %s" % (self.T, self.W, self.ACC))
+            self.out.append("v_and_b32 v%d, 0x%x, v%d" % (self.acc, (1 << self.W) - 1, self.acc))
+            self.out.append("v_mov_b32 v%d, 0" % (self.acc + 1))
+            self.tbound = self.bound >> self.W
+            self.bound = (1 << self.W) - 1
+            self.splits += 1
+        self.out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (self.ACC, a, b, self.ACC))
+        self.bound += term
+        assert self.bound < CAP
+
+    def shift(self):
+        self.out.append("v_lshrrev_b64 %s, %d, %s" % (self.ACC, self.W, self.ACC))
+        self.bound >>= self.W
+        if self.tbound is not None:
+            self.out.append("v_lshl_add_u64 %s, %s, 0, %s" % (self.ACC, self.T, self.ACC))
+            self.bound += self.tbound
+            self.tbound = None
+
+
+def gen_sqr(nl, plimbs, n0inv, W):
     """operands: %0..%{nl-1} = a (in/out VGPR), %{nl}..%{2nl-1} = p limbs (SGPR), %{2nl} = n0inv (SGPR)"""
+    MASK = (1 << W) - 1
     acc = TMP_BASE                 # v[acc:acc+1]
     a2 = TMP_BASE + 2              # nl regs
     m = a2 + nl                    # nl regs
+    treg = (m + nl + 1) & ~1      # 2 regs (64-bit aligned), only touched when a column is split
     A = lambda i: "%%%d" % i
     P = lambda i: "%%%d" % (nl + i)
     N0 = "%%%d" % (2 * nl)
-    ACC = "v[%d:%d]" % (acc, acc + 1)
     out = []
     for j in range(nl):
         out.append("v_lshlrev_b32 v%d, 1, %s" % (a2 + j, A(j)))
     out.append("v_mov_b32 v%d, 0" % acc)
     out.append("v_mov_b32 v%d, 0" % (acc + 1))
+    col = Column(out, W, acc, treg)
+    ACC = col.ACC
     for k in range(2 * nl - 1):
         j0 = 0 if k < nl else k - nl + 1
         j = j0
         while j < k - j:
-            out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, a2 + j, A(k - j), ACC))
+            col.mad("v%d" % (a2 + j), A(k - j), 2 * MASK, MASK)
             j += 1
         if k % 2 == 0:
-            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, A(k // 2), A(k // 2), ACC))
+            col.mad(A(k // 2), A(k // 2), MASK, MASK)
         if k < nl:
             for j in range(k):
                 if plimbs[k - j]:
-                    out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + j, P(k - j), ACC))
-            if n0inv == MASK:   # p = 1 mod 2^29: m = -lo mod 2^29
+                    col.mad("v%d" % (m + j), P(k - j), MASK, plimbs[k - j])
+            if n0inv == MASK:   # p = 1 mod 2^W: m = -lo mod 2^W
                 out.append("v_sub_u32 v%d, 0, v%d" % (m + k, acc))
             else:
                 out.append("v_mul_lo_u32 v%d, v%d, %s" % (m + k, acc, N0))
             out.append("v_and_b32 v%d, 0x%x, v%d" % (m + k, MASK, m + k))
-            out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + k, P(0), ACC))
+            col.mad("v%d" % (m + k), P(0), MASK, plimbs[0])
         else:
             for j in range(k - nl + 1, nl):
                 if plimbs[k - j]:
-                    out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + j, P(k - j), ACC))
+                    col.mad("v%d" % (m + j), P(k - j), MASK, plimbs[k - j])
             out.append("v_and_b32 %s, 0x%x, v%d" % (A(k - nl), MASK, acc))   # a_{k-nl} is dead from here on
-        out.append("v_lshrrev_b64 %s, %d, %s" % (ACC, W, ACC))
+        col.shift()
     out.append("v_mov_b32 %s, v%d" % (A(nl - 1), acc))
-    clob = ["v%d" % r for r in range(TMP_BASE, m + nl)] + ["vcc"]
-    return out, clob
+    # 13/14-limb fields always claim the full 30-register window (through v129 at the default base): a kernel that ends
+    # up with <= 128 VGPRs is allowed 4 wavefronts per SIMD, LDS then caps the CU at 12, and the
+    # resulting 4,4,4,0 placement is ~9 % slower than 3,3,3,3 (measured on BLS12-377, 30-bit limbs).
+    ntmp = max(treg + 2, TMP_BASE + 30) if nl >= 13 else m + nl
+    clob = ["v%d" % r for r in range(TMP_BASE, ntmp)] + ["vcc"]
+    return out, clob, col.splits
 
 
-def gen_mul(nl, plimbs, n0inv):
+def gen_mul(nl, plimbs, n0inv, W):
     """operands: %0..%{nl-1} = a (in/out VGPR), %{nl}..%{2nl-1} = b (VGPR)"""
+    MASK = (1 << W) - 1
     acc = TMP_BASE
     m = TMP_BASE + 2
+    treg = (m + nl + 1) & ~1
     A = lambda i: "%%%d" % i
     B = lambda i: "%%%d" % (nl + i)
     SP = lambda i: "s%d" % (SGPR_BASE + i)
     SN0 = "s%d" % (SGPR_BASE + nl)
-    ACC = "v[%d:%d]" % (acc, acc + 1)
     out = []
     for i in range(nl):
         out.append("s_mov_b32 %s, 0x%x" % (SP(i), plimbs[i]))
     out.append("s_mov_b32 %s, 0x%x" % (SN0, n0inv))
     out.append("v_mov_b32 v%d, 0" % acc)
     out.append("v_mov_b32 v%d, 0" % (acc + 1))
+    col = Column(out, W, acc, treg)
     for k in range(2 * nl - 1):
         j0, j1 = (0, k) if k < nl else (k - nl + 1, nl - 1)
         for j in range(j0, j1 + 1):
-            out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (ACC, A(j), B(k - j), ACC))
+            col.mad(A(j), B(k - j), MASK, MASK)
         if k < nl:
             for j in range(k):
                 if plimbs[k - j]:
-                    out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + j, SP(k - j), ACC))
+                    col.mad("v%d" % (m + j), SP(k - j), MASK, plimbs[k - j])
             if n0inv == MASK:
                 out.append("v_sub_u32 v%d, 0, v%d" % (m + k, acc))
             else:
                 out.append("v_mul_lo_u32 v%d, v%d, %s" % (m + k, acc, SN0))
             out.append("v_and_b32 v%d, 0x%x, v%d" % (m + k, MASK, m + k))
-            out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + k, SP(0), ACC))
+            col.mad("v%d" % (m + k), SP(0), MASK, plimbs[0])
         else:
             for j in range(k - nl + 1, nl):
                 if plimbs[k - j]:
-                    out.append("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (ACC, m + j, SP(k - j), ACC))
+                    col.mad("v%d" % (m + j), SP(k - j), MASK, plimbs[k - j])
             out.append("v_and_b32 %s, 0x%x, v%d" % (A(k - nl), MASK, acc))
-        out.append("v_lshrrev_b64 %s, %d, %s" % (ACC, W, ACC))
+        col.shift()
     out.append("v_mov_b32 %s, v%d" % (A(nl - 1), acc))
-    clob = ["v%d" % r for r in range(TMP_BASE, m + nl)] + ["s%d" % (SGPR_BASE + i) for i in range(nl + 1)] + ["vcc"]
-    return out, clob
+    ntmp = treg + 2 if col.splits else m + nl
+    clob = (["v%d" % r for r in range(TMP_BASE, ntmp)] + ["s%d" % (SGPR_BASE + i) for i in range(nl + 1)] + ["vcc"])
+    return out, clob, col.splits
 
 
 def emit(name, lines, outs, ins, clob):
@@ -135,30 +184,32 @@ def main():
     with open(os.path.join(ROOT, "tests", "golden", "params.json")) as f:
         params = json.load(f)
     h = ["// GENERATED by tools/gen_asm_mul.py -- do not edit.  Hand-scheduled gfx950 Montgomery squaring /",
-         "// multiplication on 29-bit limbs (product scanning, one v_mad_u64_u32 per limb product, the column",
-         "// carry is the accumulator's initial value).  See the generator's docstring.",
+         "// multiplication on unsaturated limbs (product scanning, one v_mad_u64_u32 per limb product, the",
+         "// column carry is the accumulator's initial value).  See the generator's docstring.",
          "#pragma once", "#include <hip/hip_runtime.h>", "#include <cstdint>", "namespace anemoi {",
-         "template <int FIELD> struct AsmMont29;"]
+         "template <int FIELD, int W> struct AsmMont;"]
     for fid, name in enumerate(FIELD_IDS):
         p = int(params[name]["modulus"])
-        nl, pl, n0 = field_consts(p)
-        sq, sq_clob = gen_sqr(nl, pl, n0)
-        mu, mu_clob = gen_mul(nl, pl, n0)
-        nmad = sum(1 for l in sq if l.startswith("v_mad"))
-        h.append("// %s: %d limbs; squaring %d instructions (%d v_mad_u64_u32), multiplication %d (%d)" % (
-            name, nl, len(sq), nmad, len(mu), sum(1 for l in mu if l.startswith("v_mad"))))
-        h.append("template <> struct AsmMont29<%d> {" % fid)
-        h.append("  static constexpr int NL = %d;" % nl)
-        h.append("  __device__ static __forceinline__ void sqr(uint32_t (&a)[NL]) {")
-        outs = ['"+v"(a[%d])' % i for i in range(nl)]
-        ins = ['"s"(0x%xu)' % v for v in pl] + ['"s"(0x%xu)' % n0]
-        h.append(emit("sqr", sq, outs, ins, sq_clob))
-        h.append("  }")
-        h.append("  __device__ static __forceinline__ void mul(uint32_t (&a)[NL], const uint32_t (&b)[NL]) {")
-        ins = ['"v"(b[%d])' % i for i in range(nl)]
-        h.append(emit("mul", mu, outs, ins, mu_clob))
-        h.append("  }")
-        h.append("};")
+        for W in ((29, 30) if p.bit_length() > 300 else (29,)):
+            nl, pl, n0 = field_consts(p, W)
+            sq, sq_clob, sq_splits = gen_sqr(nl, pl, n0, W)
+            mu, mu_clob, mu_splits = gen_mul(nl, pl, n0, W)
+            nmad = sum(1 for l in sq if l.startswith("v_mad"))
+            h.append("// %s, %d-bit limbs: %d limbs; squaring %d instructions (%d v_mad_u64_u32, %d split columns), "
+                     "multiplication %d (%d, %d)" % (name, W, nl, len(sq), nmad, sq_splits, len(mu),
+                                                     sum(1 for l in mu if l.startswith("v_mad")), mu_splits))
+            h.append("template <> struct AsmMont<%d, %d> {" % (fid, W))
+            h.append("  static constexpr int NL = %d;" % nl)
+            h.append("  __device__ static __forceinline__ void sqr(uint32_t (&a)[NL]) {")
+            outs = ['"+v"(a[%d])' % i for i in range(nl)]
+            ins = ['"s"(0x%xu)' % v for v in pl] + ['"s"(0x%xu)' % n0]
+            h.append(emit("sqr", sq, outs, ins, sq_clob))
+            h.append("  }")
+            h.append("  __device__ static __forceinline__ void mul(uint32_t (&a)[NL], const uint32_t (&b)[NL]) {")
+            ins = ['"v"(b[%d])' % i for i in range(nl)]
+            h.append(emit("mul", mu, outs, ins, mu_clob))
+            h.append("  }")
+            h.append("};")
     h.append("}  // namespace anemoi")
     dst = os.path.join(ROOT, "anemoi-rust_amd", "csrc", "mont29_asm_gen.h")
     with open(dst, "w") as f:
