@@ -112,11 +112,14 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
 // Flystel S-box on one column (src/traits.rs:326-358).
 // Loose bounds (units of p), entering with x, y < 2 after settle(); a Montgomery product of inputs
 // < A p and < B p is < (A B / H + 1) p with H = R'/p:
-//   381/377-bit fields (H >= 2^25, g*x by limb-wise scaling, subtraction pads with 64 p):
+//   381/377-bit fields on 29-bit limbs (H >= 2^25, g*x by limb-wise scaling, subtraction pads with 64 p):
 //     u = g*y^2 < 2g <= 30 ; x' = x + 64p - u < 66 ; t = x'^(1/alpha) < 2 ; y' = y + 64p - t < 66 ;
 //     x'' = x' + g*y'^2 + delta < 66 + 30 + 1 = 97          (every product has A B <= 66^2 << H)
-//   253..255-bit fields (H >= 70, "tight": g*x is a Montgomery product < 2p, subtraction pads with 4 p):
+//   253..255-bit fields and BLS12-377 on 30-bit limbs (H >= 70, "tight": g*x is a Montgomery product
+//   < 2p, subtraction pads with 4 p):
 //     u < 2 ; x' < 6 ; squarings of x', y' have A B = 36 <= H ; t < 2 ; y' < 6 ; x'' < 6 + 2 + 1 = 9
+//   BLS12-381 on 30-bit limbs (H = 630, g = 2 by limb-wise doubling, subtraction pads with 8 p):
+//     u < 4 ; x' < 10 ; A B = 100 <= H ; t < 2 ; y' < 10 ; x'' < 10 + 4 + 1 = 15
 template <class F, class A, int WIN>
 __device__ __forceinline__ void flystel(typename A::Fe& x, typename A::Fe& y, const PermConsts& pc,
                                         const LdsTable<A>& tab) {
@@ -138,6 +141,8 @@ __device__ __forceinline__ void flystel(typename A::Fe& x, typename A::Fe& y, co
 // only, then settle() (valid for inputs < H p = 2^25 p).
 // Tight fields, entering < 10: W=2: y < 17+.., x < 27 -> settle (27/70 + 1 < 2).  W=4: g*x < 2, so
 // x0, x1 < 12, y2, y3 < 9, PHT: < 21, < 33 -> settle (33/70 + 1 < 2); all values < 2^261.
+// BLS12-381 on 30-bit limbs, entering < 16: W=2: y < 27, x < 43.  W=4 (g = 2): x0 < 48, x1 < 112, same
+// for y, PHT: < 224, < 336 -> settle (336 <= H = 630; 336 p < 2^390).
 template <class F, class A, int W>
 __device__ __forceinline__ void mds_layer(typename A::Fe (&st)[W]) {
   if (W == 2) {

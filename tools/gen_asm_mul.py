@@ -46,9 +46,9 @@ class Column:
     """Emits the multiply-accumulates of the product columns while tracking a worst-case bound of the
     64-bit accumulator (input limbs < 2^W, reduction digits < 2^W, the actual limbs of p).  With 29-bit
     limbs every column fits.  With 30-bit limbs (13 limbs for 381/377 bits) the five middle columns do
-    not: there the accumulator is split once -- its upper part parked in T, the low W bits kept (they
-    are all that the reduction digit and the output limb look at) -- and T is added back after the
-    column's shift."""
+    not: there the accumulator is split once -- its upper word parked in T, the low word kept (the
+    reduction digit and the output limb only look at the low W bits) -- and T << (32 - W) is added
+    back after the column's shift."""
 
     def __init__(self, out, W, acc, treg):
         self.out, self.W, self.acc, self.treg = out, W, acc, treg
@@ -62,11 +62,13 @@ class Column:
         term = amax * bmax
         if self.bound + term >= CAP:
             assert self.tbound is None, "a column needs more than one split"
-            self.out.append("v_lshrrev_b64 %s, %d, %s" % (self.T, self.W, self.ACC))
-            self.out.append("v_and_b32 v%d, 0x%x, v%d" % (self.acc, (1 << self.W) - 1, self.acc))
+            # park the accumulator's upper word: column value = (T << 32) + ACC from here on
+            if self.splits == 0:
+                self.out.append("v_mov_b32 v%d, 0" % (self.treg + 1))
+            self.out.append("v_mov_b32 v%d, v%d" % (self.treg, self.acc + 1))
             self.out.append("v_mov_b32 v%d, 0" % (self.acc + 1))
-            self.tbound = self.bound >> self.W
-            self.bound = (1 << self.W) - 1
+            self.tbound = self.bound >> 32
+            self.bound = (1 << 32) - 1
             self.splits += 1
         self.out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (self.ACC, a, b, self.ACC))
         self.bound += term
@@ -76,8 +78,9 @@ class Column:
         self.out.append("v_lshrrev_b64 %s, %d, %s" % (self.ACC, self.W, self.ACC))
         self.bound >>= self.W
         if self.tbound is not None:
-            self.out.append("v_lshl_add_u64 %s, %s, 0, %s" % (self.ACC, self.T, self.ACC))
-            self.bound += self.tbound
+            self.out.append("v_lshl_add_u64 %s, %s, %d, %s" % (self.ACC, self.T, 32 - self.W, self.ACC))
+            self.bound += self.tbound << (32 - self.W)
+            assert self.bound < CAP
             self.tbound = None
 
 
