@@ -168,8 +168,8 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, prof_src)))["derived"]
             if args.batch_log2 == BATCH_LOG2:
                 traffic = pmc["hbm_traffic_bytes_per_launch"]
-            valu_busy = pmc["valu_busy_fraction"]
-            mad_frac = pmc.get("mad_issue_fraction_of_peak")
+            valu_busy = pmc["valu_issue_model_fraction"]
+            mad_frac = pmc["mad_cycle_fraction"]
         except Exception:
             prof_src = None
         total_items = n * world * args.steps
@@ -190,11 +190,13 @@ def main():
                          "kernel": "k_jive<bls12_381,2,2>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_ITEM * n},
             "alu": {"bound": "valu", "modmul_per_s": MODMUL_PER_ITEM * n / (kernel_ms * 1e-3),
-                    "valu_busy_frac_profiled": valu_busy,
-                    "mad_issue_frac_of_peak_profiled": mad_frac,
+                    "valu_issue_frac_profiled": valu_busy,
+                    "mad_cycle_frac_profiled": mad_frac,
                     "note": "384-bit Montgomery mul/sqr per second (reference chain count 9576 per compression). "
-                            "The path is VALU-issue bound: the profiled kernel keeps the vector ALUs busy in "
-                            "valu_busy_frac_profiled of all SIMD cycles (SQ_ACTIVE_INST_VALU, profiles/), see DESIGN.md"},
+                            "The path is VALU-issue bound: in the profiled kernel (SQ_INSTS_VALU, profiles/) "
+                            "v_mad_u64_u32 at 16 lanes per clock alone fills mad_cycle_frac_profiled of all SIMD "
+                            "cycles, and all VALU instructions priced at their measured issue cost fill "
+                            "valu_issue_frac_profiled; see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the judged evidence for the headline kernel on the GPU box, into gpurun_out/prof_<tag>/:
+#   bench_n1.json                 python bench.py (default flags)
+#   stats/                        rocprofv3 --kernel-trace --stats of the same bench command
+#   pmc_fetch/ pmc_write/ pmc_sq/ three separate --pmc passes (never combined with trace domains)
+# then tools/summarize_profiles.py turns them into the files kept under profiles/rNN/.
+#   tools/collect_profiles.sh <tag>
+set -o pipefail
+tag="${1:-r01}"
+out="gpurun_out/prof_${tag}"
+mkdir -p "$out"
+export TMPDIR=/tmp
+BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+python bench.py > "$out/bench_n1.json" 2> "$out/bench_n1.err" || exit 1
+tail -c 400 "$out/bench_n1.json"; echo
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- $BENCH > "$out/stats.log" 2>&1 || exit 1
+PMC="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -o run -- $PMC > "$out/pmc_fetch.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -o run -- $PMC > "$out/pmc_write.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv \
+    -d "$out/pmc_sq" -o run -- $PMC > "$out/pmc_sq.log" 2>&1 || exit 1
+python tools/summarize_profiles.py "$out" || exit 1

@@ -30,7 +30,7 @@ for fid, field in enumerate(A.FIELD_IDS):
             vals.append(((1 << k) + d) % p)
             vals.append((p - (1 << k) + d) % p)
     vals += [((1 << bits) - 1) % p, (1 << (bits - 1)) % p, p - 1, p - 2, 0, 1, 2]
-    for w in (29, 32, 58, 64):
+    for w in (29, 30, 32, 58, 60, 64):
         ones = 0
         for i in range(0, bits, 2 * w):
             ones |= ((1 << w) - 1) << i
