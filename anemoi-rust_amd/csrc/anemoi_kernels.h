@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
                                                        size_t n, PermConsts pc) {
   using F = FieldC<FIELD>;
   using C = Coop29<F>;
-  constexpr int NL = C::NL, NABI = C::NABI, R = F::kRounds21, E = 16;
+  constexpr int NL = C::NL, NABI = C::NABI, R = F::kRounds21, E = 1 << (F::kCoopWin - 1);
   __shared__ uint32_t tab[E * kBlock];
   const uint32_t lane = threadIdx.x;
   const uint32_t pl = C::konst(C::L::P), kpl = C::konst(C::L::KP), delta = C::konst(C::L::Delta);
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
       // sbox_layer (src/traits.rs:326-358)
       uint32_t t = C::mul(y, y, pl);
       x = C::sub(x, C::mul_g(t, pl), kpl);
-      // x^(1/alpha): 5-bit sliding window, table of odd powers in LDS
+      // x^(1/alpha): sliding window of F::kCoopWin bits, table of odd powers in LDS
       {
         const uint32_t x2 = C::mul(x, x, pl);
         uint32_t pw = x;
@@ -504,13 +504,18 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
           pw = C::mul(pw, x2, pl);
           tab[i * kBlock + lane] = pw;
         }
-        uint32_t acc = tab[pc.first5 * kBlock + lane];
+        uint32_t acc = tab[pc.first5 * kBlock + lane], tmp = acc;
 #pragma nounroll
         for (int s = 0; s < pc.steps5; s++) {
           const int nsq = pc.sched5[2 * s], idx = pc.sched5[2 * s + 1];
+          if (idx == 253) {  // leading-run doubling, see sliding_window() in tools/gen_params.py
+            tmp = acc;
+            continue;
+          }
 #pragma nounroll
           for (int q = 0; q < nsq; q++) acc = C::mul(acc, acc, pl);
-          if (idx != 255) acc = C::mul(acc, tab[idx * kBlock + lane], pl);
+          if (idx == 254) acc = C::mul(acc, tmp, pl);
+          else if (idx != 255) acc = C::mul(acc, tab[idx * kBlock + lane], pl);
         }
         t = acc;
       }
@@ -601,8 +606,20 @@ struct Launch {
     hc->coop_c.assign(CL::ArkC_21, CL::ArkC_21 + F::kRounds21 * CL::NL);
     hc->coop_d.assign(CL::ArkD_21, CL::ArkD_21 + F::kRounds21 * CL::NL);
     static_assert(WIN >= 2 && WIN <= 5, "schedules are generated for 2..5-bit windows");
-    hc->sched5.assign(F::kW5Sched, F::kW5Sched + 2 * F::kW5Steps);
-    hc->steps5 = F::kW5Steps, hc->first5 = F::kW5First;
+    static_assert(F::kCoopWin >= 2 && F::kCoopWin <= 5, "");
+    if (F::kCoopWin == 5) {
+      hc->sched5.assign(F::kW5Sched, F::kW5Sched + 2 * F::kW5Steps);
+      hc->steps5 = F::kW5Steps, hc->first5 = F::kW5First;
+    } else if (F::kCoopWin == 4) {
+      hc->sched5.assign(F::kW4Sched, F::kW4Sched + 2 * F::kW4Steps);
+      hc->steps5 = F::kW4Steps, hc->first5 = F::kW4First;
+    } else if (F::kCoopWin == 3) {
+      hc->sched5.assign(F::kW3Sched, F::kW3Sched + 2 * F::kW3Steps);
+      hc->steps5 = F::kW3Steps, hc->first5 = F::kW3First;
+    } else {
+      hc->sched5.assign(F::kW2Sched, F::kW2Sched + 2 * F::kW2Steps);
+      hc->steps5 = F::kW2Steps, hc->first5 = F::kW2First;
+    }
     if (WIN == 2) {
       hc->sched.assign(F::kW2Sched, F::kW2Sched + 2 * F::kW2Steps);
       hc->steps = F::kW2Steps, hc->first = F::kW2First;

@@ -62,14 +62,15 @@ struct LdsTable {
 // Per-(field, width) constants in device memory, uploaded once by the host context:
 //   ark   : C then D, each cols*rounds elements of A::NL limbs in A's Montgomery form (wave-uniform
 //           addresses -> scalar loads)
-//   sched : sliding-window schedule, pairs (squarings, table index | 255), `steps` of them
+//   sched : sliding-window schedule, pairs (squarings, op), `steps` of them; op = table index, or
+//           255 (no multiplication), 253 (tmp = acc), 254 (multiply by tmp) -- tools/gen_params.py
 struct PermConsts {
   const uint32_t* ark_c;
   const uint32_t* ark_d;
   const uint8_t* sched;
   int steps;
   int first;
-  // 5-bit-window schedule for the wave-cooperative kernels (their table costs one VGPR/LDS word per entry)
+  // schedule for the wave-cooperative kernels (window F::kCoopWin: their table costs one LDS word per entry)
   const uint8_t* sched5;
   int steps5;
   int first5;
@@ -94,12 +95,22 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
   }
   if (pc.first == 0) acc = x;
   else tab.load(pc.first, acc);
+  [[maybe_unused]] typename A::Fe tmp;  // leading-run doubling (Pallas / Vesta), see sliding_window()
+  if constexpr (F::kChainTmp) tmp = acc;
 #pragma nounroll
   for (int s = 0; s < pc.steps; s++) {
     const int nsq = pc.sched[2 * s], idx = pc.sched[2 * s + 1];
+    if constexpr (F::kChainTmp) {
+      if (idx == 253) {
+        tmp = acc;
+        continue;
+      }
+    }
 #pragma nounroll
     for (int q = 0; q < nsq; q++) A::esqr(acc, acc);
-    if (idx != 255) {
+    if (F::kChainTmp && idx == 254) {
+      A::emul(acc, acc, tmp);
+    } else if (idx != 255) {
       if (idx == 0) t = x;
       else tab.load(idx, t);
       A::emul(acc, acc, t);
