@@ -25,6 +25,18 @@ pub const ANEMOI_ERR_ARG: c_int = -3;
 pub const ANEMOI_ERR_DEVICE: c_int = -4;
 pub const ANEMOI_ERR_ALLOC: c_int = -5;
 
+/// `struct anemoi_generic_instance` of the header: NUM_COLUMNS, NUM_ROUNDS, ARK_C, ARK_D and an optional MDS
+/// matrix (null = the hard-coded `mds_layer` arm, <= 6 columns) as Montgomery limbs, i.e. `&[Felt]` pointers.
+#[repr(C)]
+pub struct AnemoiGenericInstance {
+    pub field: c_int,
+    pub num_columns: c_int,
+    pub num_rounds: c_int,
+    pub ark_c: *const u64,
+    pub ark_d: *const u64,
+    pub mds: *const u64,
+}
+
 extern "C" {
     pub fn anemoi_abi_version() -> c_int;
     pub fn anemoi_device_count() -> c_int;
@@ -49,6 +61,18 @@ extern "C" {
                                       depth: c_uint, n: usize, root: *const u64, ok: *mut u8, device: c_int) -> c_int;
     pub fn anemoi_to_montgomery(field: c_int, input: *const u64, out: *mut u64, count: usize, device: c_int) -> c_int;
     pub fn anemoi_from_montgomery(field: c_int, input: *const u64, out: *mut u64, count: usize, device: c_int) -> c_int;
+
+    // instances given by their `Anemoi` trait constants (src/traits.rs:36-76): what a new, wider instance binds
+    pub fn anemoi_generic_mds_matrix(field: c_int, num_columns: c_int, mds: *mut u64, device: c_int) -> c_int;
+    pub fn anemoi_generic_permutation_batch(inst: *const AnemoiGenericInstance, states: *mut u64, n: usize,
+                                            device: c_int) -> c_int;
+    pub fn anemoi_generic_jive_compress_k_batch(inst: *const AnemoiGenericInstance, k: c_int, input: *const u64,
+                                                out: *mut u64, n: usize, device: c_int) -> c_int;
+    pub fn anemoi_generic_hash_field_batch(inst: *const AnemoiGenericInstance, rate: c_int, elems: *const u64,
+                                           elems_per_msg: usize, n: usize, out: *mut u64, device: c_int) -> c_int;
+    pub fn anemoi_generic_hash_bytes_batch(inst: *const AnemoiGenericInstance, rate: c_int, msgs: *const u8,
+                                           msg_len: usize, n: usize, out: *mut u64, device: c_int) -> c_int;
+    pub fn anemoi_exp_alpha_batch(field: c_int, inverse: c_int, elems: *mut u64, n: usize, device: c_int) -> c_int;
 
     // buffers already in HBM; `stream` is a hipStream_t
     pub fn anemoi_jive_compress_k_dev(field: c_int, width: c_int, k: c_int, d_in: *const c_void, d_out: *mut c_void,
