@@ -53,7 +53,11 @@ struct Arith29 {
     }
   }
 
-  // Montgomery product a*b/R' mod p, result < 2p when (a/p)*(b/p) <= R'/p.  All limbs < 2^29.
+  // Montgomery product a*b/R' mod p, result < 2p when (a/p)*(b/p) <= R'/p.  All limbs < 2^W.
+  // On 30-bit limbs the generated assembly additionally assumes b < 16 p (mul) and a < 16 p (sqr): that
+  // bounds the top limb and saves column splits (tools/gen_asm_mul.py).  Every call site satisfies it: b
+  // is a table entry, a fresh product, a constant or the S-box input (< 15 p); squarings only see S-box
+  // values (< 15 p) and chain values (< 2 p).  Values up to H p (the linear layer) only enter as `a` of mul.
   //
   // Product scanning, column k:  acc_k = (acc_{k-1} >> 29) + X_k + M_k + m_k p_0  with
   //   X_k = sum_j a_j b_{k-j}            (no dependence on the reduction digits m)

@@ -84,9 +84,25 @@ class Column:
             self.tbound = None
 
 
-def gen_sqr(nl, plimbs, n0inv, W):
+def top_limb_bound(p, W, nl, mult):
+    """largest top limb of a value < mult * p whose other limbs are normalised (< 2^W)"""
+    return min((1 << W) - 1, (mult * p) >> (W * (nl - 1)))
+
+
+# Preconditions of the 30-bit-limb products (where the column bound is tight), in units of p:
+#   sqr(a):    a < 16 p   (S-box values are < 15 p, chain values < 2 p; anemoi_perm.h)
+#   mul(a, b): b < 16 p   (b is a table entry or a fresh product < 2 p, a Montgomery-form constant, or the S-box input x < 15 p)
+# They shave the top limb's contribution off columns nl-1 .. 2nl-2 and save two of the five splits in
+# the squaring, one in the multiplication.  29-bit limbs have slack and assume nothing.
+SQR_A_MULT, MUL_B_MULT = 16, 16
+
+
+def gen_sqr(nl, plimbs, n0inv, W, p=None):
     """operands: %0..%{nl-1} = a (in/out VGPR), %{nl}..%{2nl-1} = p limbs (SGPR), %{2nl} = n0inv (SGPR)"""
     MASK = (1 << W) - 1
+    amax = [MASK] * nl
+    if W >= 30:
+        amax[nl - 1] = top_limb_bound(p, W, nl, SQR_A_MULT)
     acc = TMP_BASE                 # v[acc:acc+1]
     a2 = TMP_BASE + 2              # nl regs
     m = a2 + nl                    # nl regs
@@ -105,10 +121,10 @@ def gen_sqr(nl, plimbs, n0inv, W):
         j0 = 0 if k < nl else k - nl + 1
         j = j0
         while j < k - j:
-            col.mad("v%d" % (a2 + j), A(k - j), 2 * MASK, MASK)
+            col.mad("v%d" % (a2 + j), A(k - j), 2 * amax[j], amax[k - j])
             j += 1
         if k % 2 == 0:
-            col.mad(A(k // 2), A(k // 2), MASK, MASK)
+            col.mad(A(k // 2), A(k // 2), amax[k // 2], amax[k // 2])
         if k < nl:
             for j in range(k):
                 if plimbs[k - j]:
@@ -134,9 +150,12 @@ def gen_sqr(nl, plimbs, n0inv, W):
     return out, clob, col.splits
 
 
-def gen_mul(nl, plimbs, n0inv, W):
+def gen_mul(nl, plimbs, n0inv, W, p=None):
     """operands: %0..%{nl-1} = a (in/out VGPR), %{nl}..%{2nl-1} = b (VGPR)"""
     MASK = (1 << W) - 1
+    bmax = [MASK] * nl
+    if W >= 30:
+        bmax[nl - 1] = top_limb_bound(p, W, nl, MUL_B_MULT)
     acc = TMP_BASE
     m = TMP_BASE + 2
     treg = (m + nl + 1) & ~1
@@ -154,7 +173,7 @@ def gen_mul(nl, plimbs, n0inv, W):
     for k in range(2 * nl - 1):
         j0, j1 = (0, k) if k < nl else (k - nl + 1, nl - 1)
         for j in range(j0, j1 + 1):
-            col.mad(A(j), B(k - j), MASK, MASK)
+            col.mad(A(j), B(k - j), MASK, bmax[k - j])
         if k < nl:
             for j in range(k):
                 if plimbs[k - j]:
@@ -195,8 +214,8 @@ def main():
         p = int(params[name]["modulus"])
         for W in ((29, 30) if p.bit_length() > 300 else (29,)):
             nl, pl, n0 = field_consts(p, W)
-            sq, sq_clob, sq_splits = gen_sqr(nl, pl, n0, W)
-            mu, mu_clob, mu_splits = gen_mul(nl, pl, n0, W)
+            sq, sq_clob, sq_splits = gen_sqr(nl, pl, n0, W, p)
+            mu, mu_clob, mu_splits = gen_mul(nl, pl, n0, W, p)
             nmad = sum(1 for l in sq if l.startswith("v_mad"))
             h.append("// %s, %d-bit limbs: %d limbs; squaring %d instructions (%d v_mad_u64_u32, %d split columns), "
                      "multiplication %d (%d, %d)" % (name, W, nl, len(sq), nmad, sq_splits, len(mu),
