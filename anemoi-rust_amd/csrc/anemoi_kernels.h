@@ -42,6 +42,9 @@ constexpr int kBlock = 64;  // one wavefront per workgroup: the LDS window table
 #define ANEMOI_KERNEL __global__ __launch_bounds__(kBlock)
 #endif
 
+#ifndef ANEMOI_HOLD_INPUTS_MAX_NL
+#define ANEMOI_HOLD_INPUTS_MAX_NL 13  // k_jive 2-1 keeps the feed-forward sum in VGPRs up to this many limbs
+#endif
 #ifndef ANEMOI_WIN
 #define ANEMOI_WIN 3  // 3 LDS entries per lane -> 13 waves per CU; see DESIGN.md section 3.3
 #endif
@@ -156,11 +159,11 @@ ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out,
   typename A::Fe st[W], sum[C];
   static_for<0, W>([&](auto i) { lds_get<A>(lds, threadIdx.x * W + i, st[i]); });
   __syncthreads();
-  // Jive feed-forward sum of the inputs.  9-limb fields, W = 2: kept in 9 VGPRs across the
-  // permutation (+9.6 % on Jubjub against re-reading, A/B in one process).  Otherwise the inputs are
-  // fetched again at the end (from L2 / Infinity Cache: measured HBM traffic 1.4x the algorithmic
-  // bytes): holding 14 VGPRs costs the BLS12-381 2-1 kernel 1.2 %, and the W = 4 kernels would spill.
-  constexpr bool kHoldInputs = W == 2 && A::NL <= 9;
+  // Jive feed-forward sum of the inputs.  W = 2: one element, kept in VGPRs across the permutation
+  // (+9.6 % on Jubjub against re-reading; on the 13-limb layout 138 instead of 130 VGPRs, same speed,
+  // and the HBM traffic drops from 1.43x to the algorithmic bytes).  The W = 4 one-state-per-lane kernel
+  // would spill, so it fetches the inputs again at the end (from L2 / Infinity Cache).
+  constexpr bool kHoldInputs = W == 2 && A::NL <= ANEMOI_HOLD_INPUTS_MAX_NL;
   typename A::Fe insum[kHoldInputs ? C : 1];
   if constexpr (kHoldInputs) {
 #pragma unroll
