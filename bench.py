@@ -115,6 +115,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            try:  # create the RCCL communicator now, outside the timed region
+                dist.barrier()
+            except Exception as e:  # the data path has no collective: the control plane may fall back to gloo
+                sys.stderr.write("rank %d: RCCL barrier failed (%s); control plane falls back to gloo\n" % (rank, e))
+                dist.destroy_process_group()
+                backend = "gloo"
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
