@@ -1,0 +1,202 @@
+"""Executes the GENERATED gfx950 assembly of the Montgomery squaring / multiplication
+(anemoi-rust_amd/csrc/mont29_asm_gen.h, tools/gen_asm_mul.py) on a small CPU interpreter of the few
+instructions it uses, with overflow detection on every v_mad_u64_u32 / v_lshl_add_u64.
+
+Why: the GPU parity tests feed random field elements, which never come near the worst-case limb
+patterns the 64-bit column accumulators are dimensioned for (30-bit limbs: a column holds up to 26
+products of 2^60 and is split where it could overflow).  Here every statement is run on adversarial
+inputs -- all limbs at their maximum, the top limb at its documented bound -- and the result must be
+the Montgomery product (value-level, any representative below 2^(W NL)) with limbs below 2^W.
+CPU only, no GPU and no oracle involved: this pins the generator's bound bookkeeping.
+"""
+import json
+import os
+import random
+import re
+
+import pytest
+
+from conftest import FIELD_IDS, ROOT
+
+HDR = os.path.join(ROOT, "anemoi-rust_amd", "csrc", "mont29_asm_gen.h")
+M32, M64 = (1 << 32) - 1, (1 << 64) - 1
+
+
+def parse_header():
+    """{(field_id, W): {"NL": nl, "sqr": (lines, operands), "mul": (lines, operands)}}"""
+    text = open(HDR).read()
+    out = {}
+    for m in re.finditer(r"template <> struct AsmMont<(\d+), (\d+)> \{(.*?)\n\};", text, re.S):
+        fid, W, body = int(m.group(1)), int(m.group(2)), m.group(3)
+        nl = int(re.search(r"NL = (\d+);", body).group(1))
+        entry = {"NL": nl}
+        for name in ("sqr", "mul"):
+            fn = re.search(r"void %s\(.*?asm volatile\((.*?)\);\s*\}" % name, body, re.S).group(1)
+            lines = re.findall(r'"([^"]+?)\\n\\t"', fn)
+            tail = fn[fn.rindex('\\n\\t"') + 5:]
+            parts = [s.strip() for s in tail.split("\n") if s.strip().startswith(":")]
+            outs = re.findall(r'"\+v"\((\w+)\[(\d+)\]\)', parts[0])
+            ins = re.findall(r'"(s|v)"\((?:0x([0-9a-f]+)u|(\w+)\[(\d+)\])\)', parts[1])
+            entry[name] = (lines, outs, ins)
+        out[(fid, W)] = entry
+    return out
+
+
+class Overflow(Exception):
+    pass
+
+
+def run(lines, outs, ins, a, b=None):
+    """interpret one asm statement; a, b = limb lists; returns the new a"""
+    ops = {}  # "%k" -> ("a", i) | ("b", i) | ("const", value)
+    for k, (_, i) in enumerate(outs):
+        ops["%%%d" % k] = ("a", int(i))
+    for k, (_, hexv, arr, idx) in enumerate(ins):
+        ops["%%%d" % (len(outs) + k)] = ("const", int(hexv, 16)) if hexv else ("b", int(idx))
+    a, b = list(a), list(b) if b is not None else None
+    reg = {}
+
+    def rd(tok):
+        tok = tok.strip()
+        if tok in ops:
+            kind, v = ops[tok]
+            return a[v] if kind == "a" else b[v] if kind == "b" else v
+        if tok.startswith("0x"):
+            return int(tok, 16)
+        if re.fullmatch(r"-?\d+", tok):
+            return int(tok) & M32
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            lo = int(m.group(1))
+            return reg.get("v%d" % lo, 0) | (reg.get("v%d" % (lo + 1), 0) << 32)
+        return reg[tok]  # vN / sN: KeyError = read before write
+
+    def wr(tok, val):
+        tok = tok.strip()
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            lo = int(m.group(1))
+            reg["v%d" % lo], reg["v%d" % (lo + 1)] = val & M32, (val >> 32) & M32
+        elif tok in ops:
+            kind, v = ops[tok]
+            assert kind == "a"
+            a[v] = val & M32
+        else:
+            reg[tok] = val & M32
+
+    for ln in lines:
+        op, rest = ln.split(None, 1)
+        # split operands, keeping v[lo:hi] together
+        args = [x.strip() for x in re.split(r",\s*(?![^\[]*\])", rest)]
+        if op == "v_mad_u64_u32":
+            d, _vcc, s0, s1, s2 = args
+            val = rd(s0) * rd(s1) + rd(s2)
+            if val > M64:
+                raise Overflow(ln)
+            wr(d, val)
+        elif op == "v_lshl_add_u64":
+            d, s0, sh, s2 = args
+            val = (rd(s0) << rd(sh)) + rd(s2)
+            if val > M64:
+                raise Overflow(ln)
+            wr(d, val)
+        elif op == "v_lshrrev_b64":
+            d, sh, s = args
+            wr(d, rd(s) >> rd(sh))
+        elif op == "v_lshlrev_b32":
+            d, sh, s = args
+            val = rd(s) << rd(sh)
+            if val > M32:
+                raise Overflow(ln)
+            wr(d, val)
+        elif op == "v_and_b32":
+            d, s0, s1 = args
+            wr(d, rd(s0) & rd(s1))
+        elif op in ("v_mov_b32", "s_mov_b32"):
+            d, s = args
+            wr(d, rd(s))
+        elif op == "v_mul_lo_u32":
+            d, s0, s1 = args
+            wr(d, (rd(s0) * rd(s1)) & M32)
+        elif op == "v_sub_u32":
+            d, s0, s1 = args
+            wr(d, (rd(s0) - rd(s1)) & M32)
+        else:
+            raise AssertionError("instruction not modelled: " + ln)
+    return a
+
+
+def value(limbs, W):
+    return sum(v << (W * i) for i, v in enumerate(limbs))
+
+
+def limbs_of(v, W, nl):
+    return [(v >> (W * i)) & ((1 << W) - 1) for i in range(nl)]
+
+
+@pytest.fixture(scope="module")
+def asm():
+    return parse_header()
+
+
+@pytest.fixture(scope="module")
+def moduli():
+    with open(os.path.join(ROOT, "tests", "golden", "params.json")) as f:
+        P = json.load(f)
+    return [int(P[name]["modulus"]) for name in FIELD_IDS]
+
+
+def adversarial(p, W, nl, mult, rng):
+    """limb vectors at the edge of what the statement may be given: values below mult * p with as many
+    limbs at their maximum as that allows"""
+    full = (1 << W) - 1
+    top = min(full, max(((mult * p) >> (W * (nl - 1))) - 1, 0))
+    pats = [[full] * (nl - 1) + [top], [full] * (nl - 1) + [0], [0] * nl, [1] + [0] * (nl - 1),
+            [full if i % 2 else 0 for i in range(nl - 1)] + [top], limbs_of(p - 1, W, nl), limbs_of(p, W, nl),
+            limbs_of(mult * p - 1, W, nl)]
+    for _ in range(6):
+        pats.append([rng.randrange(full + 1) for _ in range(nl - 1)] + [rng.randrange(top + 1)])
+    assert all(value(v, W) < mult * p for v in pats)
+    return pats
+
+
+def test_every_layout_is_present(asm):
+    assert sorted(asm) == sorted([(f, 29) for f in range(7)] + [(0, 30), (1, 30)])
+
+
+@pytest.mark.parametrize("key", [(f, 29) for f in range(7)] + [(0, 30), (1, 30)])
+def test_generated_products_on_adversarial_limbs(asm, moduli, key):
+    fid, W = key
+    e, p = asm[key], moduli[fid]
+    nl = e["NL"]
+    Rinv = pow(1 << (W * nl), -1, p)
+    rng = random.Random(fid * 100 + W)
+    # contract (mont29.h): a product of inputs < A p and < B p with A B <= H = R'/p is below 2p; on 30-bit
+    # limbs additionally a < 16 p (squaring) / b < 16 p (multiplication)
+    H = (1 << (W * nl)) // p
+    import math
+    A = min(math.isqrt(H), 16 if W >= 30 else 1 << 12)
+    lines, outs, ins = e["sqr"]
+    for a in adversarial(p, W, nl, A, rng):
+        r = run(lines, outs, ins, a)
+        assert all(0 <= v < (1 << W) for v in r)
+        assert value(r, W) % p == value(a, W) ** 2 * Rinv % p
+        assert value(r, W) < 2 * p
+    B = min(math.isqrt(H), 16)
+    A = min(H // B, 1 << 20)       # `a` may be as large as the linear layer's values: A B <= H is all it needs
+    lines, outs, ins = e["mul"]
+    for a in adversarial(p, W, nl, A, rng):
+        for b in adversarial(p, W, nl, B, rng)[:6]:
+            r = run(lines, outs, ins, a, b)
+            assert all(0 <= v < (1 << W) for v in r)
+            assert value(r, W) % p == value(a, W) * value(b, W) * Rinv % p
+            assert value(r, W) < 2 * p
+
+
+def test_the_interpreter_notices_an_overflow():
+    """sanity of the checker itself: five 32x32-bit products of all ones do not fit a 64-bit accumulator"""
+    lines = ["v_mov_b32 v100, 0", "v_mov_b32 v101, 0"] + ["v_mad_u64_u32 v[100:101], vcc, %0, %0, v[100:101]"] * 5
+    outs = [("a", "0")]
+    assert run(lines[:3], outs, [], [M32]) == [M32]
+    with pytest.raises(Overflow):
+        run(lines, outs, [], [M32])
