@@ -170,21 +170,12 @@ int for_devices(int device, size_t n, Body body) {
   return ANEMOI_OK;
 }
 
-// Generic host-pointer batch: copy `in_per_item` bytes per item in, run `launch`, copy out.
-// The code can cut a batch into chunks on two streams (copy of chunk i+1 under the kernel of chunk i),
-// but it is switched off (kHostChunks = 1): measured on 2^20 BLS12-381 compressions from pageable
-// memory, 8 chunks took 138.8 ms against 130.2 ms unchunked (kernel 119.6 ms) -- every chunk ends in
-// a partially filled wave of workgroups on this ALU-bound kernel, which costs more than the ~10 ms of
-// copies that could be hidden.
-constexpr size_t kHostChunks = 1;
-struct StreamPair {
-  hipStream_t s[2] = {nullptr, nullptr};
-  ~StreamPair() {
-    for (auto x : s)
-      if (x) (void)hipStreamDestroy(x);
-  }
-};
-
+// Generic host-pointer batch: copy `in_per_item` bytes per item in, run `launch`, copy out, all on the
+// device's default stream.  Cutting a batch into chunks on two streams (copy of chunk i+1 under the
+// kernel of chunk i) was measured and dropped: 2^20 BLS12-381 compressions from pageable memory took
+// 138.8 ms in 8 chunks against 130.2 ms unchunked (kernel 119.6 ms) -- every chunk ends in a partially
+// filled wave of workgroups on this ALU-bound kernel, which costs more than the ~10 ms of copies that
+// could be hidden.
 template <class LaunchFn>
 int host_batch(int device, size_t n, const void* in, size_t in_per_item, void* out, size_t out_per_item,
                LaunchFn launch) {
@@ -200,39 +191,13 @@ int host_batch(int device, size_t n, const void* in, size_t in_per_item, void* o
       rc = dout.alloc(count * out_per_item);
       if (rc) return rc;
     }
-    char* o = (char*)(out != in ? dout.p : din.p);
-    const char* hin = (const char*)in + first * in_per_item;
-    char* hout = (char*)out + first * out_per_item;
-    // chunking: kHostChunks chunks, each a multiple of the 64-item workgroup, only for big batches
-    size_t chunk = count;
-    if (kHostChunks > 1 && count >= (size_t(1) << 17))
-      chunk = ((count + kHostChunks - 1) / kHostChunks + 63) / 64 * 64;
-    StreamPair sp;
-    if (chunk < count) {
-      HIP_TRY(hipStreamCreateWithFlags(&sp.s[0], hipStreamNonBlocking));
-      HIP_TRY(hipStreamCreateWithFlags(&sp.s[1], hipStreamNonBlocking));
-    }
-    int c = 0;
-    for (size_t b = 0; b < count; b += chunk, c++) {
-      const size_t m = count - b < chunk ? count - b : chunk;
-      hipStream_t s = sp.s[c & 1];
-      HIP_TRY(hipMemcpyAsync((char*)din.p + b * in_per_item, hin + b * in_per_item, m * in_per_item,
-                             hipMemcpyHostToDevice, s));
-      rc = launch((char*)din.p + b * in_per_item, o + b * out_per_item, m, s);
-      if (rc) return rc;
-    }
-    c = 0;
-    for (size_t b = 0; b < count; b += chunk, c++) {
-      const size_t m = count - b < chunk ? count - b : chunk;
-      HIP_TRY(hipMemcpyAsync(hout + b * out_per_item, o + b * out_per_item, m * out_per_item, hipMemcpyDeviceToHost,
-                             sp.s[c & 1]));
-    }
-    if (sp.s[0]) {
-      HIP_TRY(hipStreamSynchronize(sp.s[0]));
-      HIP_TRY(hipStreamSynchronize(sp.s[1]));
-    } else {
-      HIP_TRY(hipStreamSynchronize(nullptr));
-    }
+    void* o = out != in ? dout.p : din.p;
+    HIP_TRY(hipMemcpyAsync(din.p, (const char*)in + first * in_per_item, count * in_per_item, hipMemcpyHostToDevice,
+                           nullptr));
+    rc = launch(din.p, o, count, (hipStream_t) nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync((char*)out + first * out_per_item, o, count * out_per_item, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return ANEMOI_OK;
   });
 }
