@@ -510,7 +510,8 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
         uint32_t acc = tab[pc.first5 * kBlock + lane], tmp = acc;
 #pragma nounroll
         for (int s = 0; s < pc.steps5; s++) {
-          const int nsq = pc.sched5[2 * s], idx = pc.sched5[2 * s + 1];
+          const uint32_t word = pc.sched5[s];
+          const int nsq = word & 0xff, idx = word >> 8;
           if (idx == 253) {  // leading-run doubling, see sliding_window() in tools/gen_params.py
             tmp = acc;
             continue;

@@ -62,16 +62,18 @@ struct LdsTable {
 // Per-(field, width) constants in device memory, uploaded once by the host context:
 //   ark   : C then D, each cols*rounds elements of A::NL limbs in A's Montgomery form (wave-uniform
 //           addresses -> scalar loads)
-//   sched : sliding-window schedule, pairs (squarings, op), `steps` of them; op = table index, or
-//           255 (no multiplication), 253 (tmp = acc), 254 (multiply by tmp) -- tools/gen_params.py
+//   sched : sliding-window schedule, `steps` words (squarings | op << 8); op = table index, or 255
+//           (no multiplication), 253 (tmp = acc), 254 (multiply by tmp) -- tools/gen_params.py.  One
+//           32-bit word per step so that the wave-uniform fetch is a scalar load (s_load_dword):
+//           byte entries made hipcc fetch them with a vector load and wait for it on every step
 struct PermConsts {
   const uint32_t* ark_c;
   const uint32_t* ark_d;
-  const uint8_t* sched;
+  const uint32_t* sched;
   int steps;
   int first;
   // schedule for the wave-cooperative kernels (window F::kCoopWin: their table costs one LDS word per entry)
-  const uint8_t* sched5;
+  const uint32_t* sched5;
   int steps5;
   int first5;
   // Anemoi-2-1 round constants in the cooperative kernels' limb layout (F::Coop)
@@ -99,7 +101,8 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
   if constexpr (F::kChainTmp) tmp = acc;
 #pragma nounroll
   for (int s = 0; s < pc.steps; s++) {
-    const int nsq = pc.sched[2 * s], idx = pc.sched[2 * s + 1];
+    const uint32_t word = pc.sched[s];
+    const int nsq = word & 0xff, idx = word >> 8;
     if constexpr (F::kChainTmp) {
       if (idx == 253) {
         tmp = acc;

@@ -65,29 +65,31 @@ int get_consts(int field, int width, PermConsts* out) {
   if (!c.ready[field][wi]) {
     anemoi::HostConsts hc;
     anemoi::field_ops(field)->host_consts(width, &hc);
-    const size_t ab = hc.ark_c.size() * sizeof(uint32_t), sb = hc.sched.size(), sb5 = (hc.sched5.size() + 3) / 4 * 4;
-    const size_t cb = hc.coop_c.size() * sizeof(uint32_t);
+    // schedules go up as one 32-bit word per step (squarings | op << 8): scalar loads in the kernels
+    auto words = [](const std::vector<uint8_t>& pairs) {
+      std::vector<uint32_t> w(pairs.size() / 2);
+      for (size_t i = 0; i < w.size(); i++) w[i] = uint32_t(pairs[2 * i]) | (uint32_t(pairs[2 * i + 1]) << 8);
+      return w;
+    };
+    const std::vector<uint32_t> s3 = words(hc.sched), s5 = words(hc.sched5);
+    const std::vector<uint32_t>* parts[6] = {&hc.ark_c, &hc.ark_d, &s3, &s5, &hc.coop_c, &hc.coop_d};
+    size_t off[7] = {0};
+    for (int i = 0; i < 6; i++) off[i + 1] = off[i] + parts[i]->size() * sizeof(uint32_t);
     char* blob = nullptr;
-    static_assert(sizeof(uint32_t) == 4, "");
-    const size_t sbp = (sb + 3) / 4 * 4;  // keep the 32-bit tables behind the byte schedules aligned
-    HIP_TRY(hipMalloc((void**)&blob, 2 * ab + sbp + sb5 + 2 * cb));
-    HIP_TRY(hipMemcpy(blob, hc.ark_c.data(), ab, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(blob + ab, hc.ark_d.data(), ab, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(blob + 2 * ab, hc.sched.data(), sb, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(blob + 2 * ab + sbp, hc.sched5.data(), hc.sched5.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(blob + 2 * ab + sbp + sb5, hc.coop_c.data(), cb, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(blob + 2 * ab + sbp + sb5 + cb, hc.coop_d.data(), cb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&blob, off[6]));
+    for (int i = 0; i < 6; i++)
+      HIP_TRY(hipMemcpy(blob + off[i], parts[i]->data(), parts[i]->size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     PermConsts pc;
-    pc.ark_c = (const uint32_t*)blob;
-    pc.ark_d = (const uint32_t*)(blob + ab);
-    pc.sched = (const uint8_t*)(blob + 2 * ab);
+    pc.ark_c = (const uint32_t*)(blob + off[0]);
+    pc.ark_d = (const uint32_t*)(blob + off[1]);
+    pc.sched = (const uint32_t*)(blob + off[2]);
     pc.steps = hc.steps;
     pc.first = hc.first;
-    pc.sched5 = (const uint8_t*)(blob + 2 * ab + sbp);
+    pc.sched5 = (const uint32_t*)(blob + off[3]);
     pc.steps5 = hc.steps5;
     pc.first5 = hc.first5;
-    pc.coop_c = (const uint32_t*)(blob + 2 * ab + sbp + sb5);
-    pc.coop_d = (const uint32_t*)(blob + 2 * ab + sbp + sb5 + cb);
+    pc.coop_c = (const uint32_t*)(blob + off[4]);
+    pc.coop_d = (const uint32_t*)(blob + off[5]);
     c.pc[field][wi] = pc;
     c.ready[field][wi] = true;
   }
