@@ -22,6 +22,7 @@
 #include <cstdint>
 
 #include "field_consts_gen.h"
+#include "mont29.h"  // ANEMOI_ASM_MUL and the generated assembly (mont29_asm_gen.h)
 
 namespace anemoi {
 
@@ -76,8 +77,13 @@ struct Coop29 {
 
   // Montgomery product (limbs of a, b < 2^29 + 2^7): result < 2p when (a/p)(b/p) <= R'/p
   __device__ static __forceinline__ uint32_t mul(uint32_t a, uint32_t b, uint32_t pl) {
-    uint64_t t = 0;
     const uint32_t sh = lane() == 0 ? 29u : 63u;
+#if ANEMOI_ASM_MUL
+    // the same scan as below, hand-scheduled (tools/gen_asm_mul.py gen_coop_mul: 10 issue slots per step
+    // instead of hipcc's 13)
+    return settle_columns(AsmCoop<F::kId>::mul(a, b, pl, sh));
+#endif
+    uint64_t t = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
       const uint32_t ai = __builtin_amdgcn_readlane(a, i);

@@ -196,6 +196,53 @@ def gen_mul(nl, plimbs, n0inv, W, p=None):
     return out, clob, col.splits
 
 
+COOP_VBASE, COOP_SBASE = 60, 60   # fixed (clobbered) registers of the cooperative product
+
+
+def gen_coop_mul(nl, n0inv, W=29):
+    """Wave-cooperative Montgomery product of coop29.h (one W-bit limb per lane, lanes 0..nl-1 of a DPP row)
+    as one asm statement.  Operands: %0 = t.lo (out), %1 = t.hi (out), %2 = a, %3 = b, %4 = p limb of this
+    lane, %5 = per-lane shift amount (W in lane 0, 63 elsewhere).  Per step i:
+        T += a_i * b                       a_i: SGPR, all nl of them broadcast up front with v_readlane
+        m  = -(T_lane0.lo) / p mod 2^W     v_readlane -> scalar multiply / mask
+        T += m * p_lane
+        U  = T >> shift                    lane 0: the retired column's carry; other lanes: 0 (T < 2^63)
+        T  = T_{lane+1} + U                v_add_co_u32 / v_addc_co_u32 with DPP row_shl:1 on src0
+    hipcc's version of the same step needs 13 issue slots (separate DPP moves, a 64-bit add and an extra
+    hazard nop after each broadcast); this one 10.  Hazard slots written out by hand: VALU-written VGPR
+    -> v_readlane (1), VALU-written VGPR -> DPP source (2, one of them filled by the shift)."""
+    MASK = (1 << W) - 1
+    T, U = COOP_VBASE, COOP_VBASE + 2
+    TT, UU = "v[%d:%d]" % (T, T + 1), "v[%d:%d]" % (U, U + 1)
+    SA = lambda i: "s%d" % (COOP_SBASE + i)
+    SM = "s%d" % (COOP_SBASE + nl)
+    dpp = "row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    out = ["s_nop 1"]   # whatever VALU wrote `a` last: settled before the first v_readlane
+    for i in range(nl):
+        out.append("v_readlane_b32 %s, %%2, %d" % (SA(i), i))
+    out.append("s_nop 1")
+    for i in range(nl):
+        out.append("v_mad_u64_u32 %s, vcc, %s, %%3, %s" % (TT, SA(i), TT if i else "0"))
+        out.append("s_nop 0")
+        out.append("v_readlane_b32 %s, v%d, 0" % (SM, T))
+        if n0inv == MASK:
+            out.append("s_sub_i32 %s, 0, %s" % (SM, SM))
+        else:
+            out.append("s_mul_i32 %s, %s, 0x%x" % (SM, SM, n0inv))
+        out.append("s_and_b32 %s, %s, 0x%x" % (SM, SM, MASK))
+        out.append("v_mad_u64_u32 %s, vcc, %s, %%4, %s" % (TT, SM, TT))
+        out.append("v_lshrrev_b64 %s, %%5, %s" % (UU, TT))
+        out.append("s_nop 0")
+        out.append("v_add_co_u32_dpp v%d, vcc, v%d, v%d %s" % (T, T, U, dpp))
+        out.append("v_addc_co_u32_dpp v%d, vcc, v%d, v%d, vcc %s" % (T + 1, T + 1, U + 1, dpp))
+    out.append("v_mov_b32 %%0, v%d" % T)
+    out.append("v_mov_b32 %%1, v%d" % (T + 1))
+    out.append("s_nop 1")  # the caller's next instructions read the results through DPP
+    clob = (["v%d" % r for r in range(COOP_VBASE, COOP_VBASE + 4)] +
+            ["s%d" % (COOP_SBASE + i) for i in range(nl + 1)] + ["vcc"])
+    return out, clob
+
+
 def emit(name, lines, outs, ins, clob):
     body = "\n".join('        "%s\\n\\t"' % l for l in lines)
     return ("    asm volatile(\n%s\n        : %s\n        : %s\n        : %s);\n"
@@ -232,6 +279,20 @@ def main():
             h.append(emit("mul", mu, outs, ins, mu_clob))
             h.append("  }")
             h.append("};")
+    h.append("// Wave-cooperative product (coop29.h), always on 29-bit limbs: see gen_coop_mul() in the generator.")
+    h.append("template <int FIELD> struct AsmCoop;")
+    for fid, name in enumerate(FIELD_IDS):
+        p = int(params[name]["modulus"])
+        nl, pl, n0 = field_consts(p, 29)
+        co, co_clob = gen_coop_mul(nl, n0)
+        h.append("// %s: %d steps, %d instructions" % (name, nl, len(co)))
+        h.append("template <> struct AsmCoop<%d> {" % fid)
+        h.append("  __device__ static __forceinline__ uint64_t mul(uint32_t a, uint32_t b, uint32_t pl, uint32_t sh) {")
+        h.append("    uint32_t lo, hi;")
+        h.append(emit("coop", co, ['"=&v"(lo)', '"=&v"(hi)'], ['"v"(a)', '"v"(b)', '"v"(pl)', '"v"(sh)'], co_clob))
+        h.append("    return ((uint64_t)hi << 32) | lo;")
+        h.append("  }")
+        h.append("};")
     h.append("}  // namespace anemoi")
     dst = os.path.join(ROOT, "anemoi-rust_amd", "csrc", "mont29_asm_gen.h")
     with open(dst, "w") as f:
