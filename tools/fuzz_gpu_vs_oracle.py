@@ -2,7 +2,7 @@
 """One-off differential fuzz: many random and structured states per field through the GPU kernels
 (lane-private and wave-cooperative Jive 2-1, Jive 4-3, permutation) against the C oracle.
 Structured states stress carry patterns: limbs of all ones, values next to p and to 2^k, sparse values.
-    python tools/fuzz_gpu_vs_oracle.py [items_per_field]"""
+    python tools/fuzz_gpu_vs_oracle.py [items_per_field] [seed]"""
 import os
 import random
 import sys
@@ -16,13 +16,14 @@ import orc
 import anemoi_amd as A
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 params = json.load(open(os.path.join(ROOT, "tests", "golden", "params.json")))
 oracle = orc.Oracle()
 threads = 16
 bad = 0
 for fid, field in enumerate(A.FIELD_IDS):
     p, L = int(params[field]["modulus"]), params[field]["u64_limbs"]
-    rng = random.Random(1000 + fid)
+    rng = random.Random(1000 * seed + fid)
     vals = []
     bits = p.bit_length()
     for k in range(0, bits, 7):
