@@ -204,17 +204,7 @@ ANEMOI_KERNEL void k_sponge_cols(const void* __restrict__ src, size_t per_msg, s
 #pragma nounroll
   for (size_t e = 0; e < total; e++) {
     typename A::Fe el, t;
-    if (e < num) {
-      if (BYTES) {
-        const size_t off = e * F::kChunk;
-        const size_t left = per_msg - off;
-        chunk_to_fe<F, A>(el, msg + off, left < size_t(F::kChunk) ? int(left) : F::kChunk);
-      } else {
-        load_abi<A>(el, (const uint32_t*)msg + e * A::NABI);
-      }
-    } else {
-      A::set_one(el);
-    }
+    sponge_element<F, A, BYTES>(el, msg, e, num, per_msg);
     A::add(t, x, el);
     fe_select<A>(x, pos < c && geo.col == pos, t, x);
     A::add(t, y, el);

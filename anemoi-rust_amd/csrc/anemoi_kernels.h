@@ -222,6 +222,28 @@ __device__ __forceinline__ void chunk_to_fe(typename A::Fe& e, const uint8_t* __
   A::from_int(e, w);
 }
 
+// Element e of a message as the sponge absorbs it: chunk e of a byte message (BYTES) or ABI element e,
+// and the padding element 1 once the message is exhausted (e == num, only when num % RATE != 0).
+template <class F, class A, bool BYTES>
+__device__ __forceinline__ void sponge_element(typename A::Fe& el, const uint8_t* __restrict__ msg, size_t e, size_t num,
+                                               size_t per_msg) {
+  if (e < num) {
+    if (BYTES) {
+      const size_t off = e * F::kChunk;
+      const size_t left = per_msg - off;
+      chunk_to_fe<F, A>(el, msg + off, left < size_t(F::kChunk) ? int(left) : F::kChunk);
+    } else {
+      const uint32_t* src32 = (const uint32_t*)msg + e * A::NABI;
+      uint32_t w[A::NABI];
+#pragma unroll
+      for (int l = 0; l < A::NABI; l++) w[l] = src32[l];
+      A::from_abi(el, w);
+    }
+  } else {
+    A::set_one(el);
+  }
+}
+
 // Sponge over `num` elements per message (BYTES: taken from msg_len-byte messages; else ABI
 // elements).  Unified rule (== both hasher.rs variants): absorb into state[i]; permute when
 // i == RATE; if num % RATE != 0 absorb a final 1 and permute; digest = state[0].
@@ -245,21 +267,7 @@ ANEMOI_KERNEL void k_sponge(const void* __restrict__ src, size_t per_msg, size_t
 #pragma nounroll
   for (size_t e = 0; e < total; e++) {
     typename A::Fe el;
-    if (e < num) {
-      if (BYTES) {
-        const size_t off = e * F::kChunk;
-        const size_t left = per_msg - off;
-        chunk_to_fe<F, A>(el, msg + off, left < size_t(F::kChunk) ? int(left) : F::kChunk);
-      } else {
-        const uint32_t* src32 = (const uint32_t*)msg + e * A::NABI;
-        uint32_t w[A::NABI];
-#pragma unroll
-        for (int l = 0; l < A::NABI; l++) w[l] = src32[l];
-        A::from_abi(el, w);
-      }
-    } else {
-      A::set_one(el);
-    }
+    sponge_element<F, A, BYTES>(el, msg, e, num, per_msg);
     // pos is wave-uniform (every message has the same length)
     if (RATE == 1 || pos == 0) A::add(st[0], st[0], el);
     else if (pos == 1) A::add(st[1], st[1], el);
@@ -365,21 +373,7 @@ ANEMOI_KERNEL void k_sponge_pair(const void* __restrict__ src, size_t per_msg, s
 #pragma nounroll
   for (size_t e = 0; e < total; e++) {
     typename A::Fe el, t;
-    if (e < num) {
-      if (BYTES) {
-        const size_t off = e * F::kChunk;
-        const size_t left = per_msg - off;
-        chunk_to_fe<F, A>(el, msg + off, left < size_t(F::kChunk) ? int(left) : F::kChunk);
-      } else {
-        const uint32_t* src32 = (const uint32_t*)msg + e * A::NABI;
-        uint32_t w[A::NABI];
-#pragma unroll
-        for (int l = 0; l < A::NABI; l++) w[l] = src32[l];
-        A::from_abi(el, w);
-      }
-    } else {
-      A::set_one(el);
-    }
+    sponge_element<F, A, BYTES>(el, msg, e, num, per_msg);
     // pos is wave-uniform: state[0] -> even.x, state[1] -> odd.x, state[2] -> even.y
     if (pos < 2) {
       A::add(t, x, el);
