@@ -77,6 +77,9 @@ _SIGS = {
     "anemoi_merkle_path": ([_int, _u64p, ctypes.c_uint, _sz, _u64p], _int),
     "anemoi_merkle_verify_batch": ([_int, _u64p, _u64p, _u64p, ctypes.c_uint, _sz, _u64p, _u8p, _int], _int),
     "anemoi_merkle_root_arity4": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
+    "anemoi_merkle_tree_arity4": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
+    "anemoi_merkle_path_arity4": ([_int, _u64p, ctypes.c_uint, _sz, _u64p], _int),
+    "anemoi_merkle_verify_arity4_batch": ([_int, _u64p, _u64p, _u64p, ctypes.c_uint, _sz, _u64p, _u8p, _int], _int),
     "anemoi_merkle_tree_dev": ([_int, _vp, ctypes.c_uint, _vp, _vp], _int),
     "anemoi_merkle_climb_dev": ([_int, _vp, _vp, _vp, ctypes.c_uint, _sz, _vp, _vp], _int),
     "anemoi_to_montgomery": ([_int, _u64p, _u64p, _sz, _int], _int),
@@ -298,6 +301,35 @@ class Anemoi:
         out = np.empty(self.limbs, dtype=np.uint64)
         _check(lib.anemoi_merkle_root_arity4(self.field, _p64(lv), depth4, _p64(out), self.device))
         return out
+
+    def merkle_tree_arity4(self, leaves, depth4):
+        """All levels of the arity-4 tree: list [leaves, level1, ..., [root]] of numpy arrays."""
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, self.limbs)
+        if len(lv) != 1 << (2 * depth4):
+            raise AnemoiError(-3)
+        flat = np.empty((((len(lv) << 2) - 1) // 3, self.limbs), dtype=np.uint64)
+        _check(lib.anemoi_merkle_tree_arity4(self.field, _p64(lv), depth4, _p64(flat), self.device))
+        out, off = [], 0
+        for l in range(depth4 + 1):
+            out.append(flat[off: off + (1 << (2 * (depth4 - l)))])
+            off += 1 << (2 * (depth4 - l))
+        return out
+
+    def merkle_path_arity4(self, tree_levels, depth4, index):
+        flat = np.ascontiguousarray(np.concatenate(tree_levels), dtype=np.uint64)
+        path = np.empty((3 * depth4, self.limbs), dtype=np.uint64)
+        _check(lib.anemoi_merkle_path_arity4(self.field, _p64(flat), depth4, index, _p64(path) if depth4 else None))
+        return path
+
+    def merkle_verify_arity4_batch(self, leaves, indices, paths, depth4, root):
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64).reshape(-1, self.limbs)
+        ix = np.ascontiguousarray(indices, dtype=np.uint64)
+        pa = np.ascontiguousarray(paths, dtype=np.uint64).reshape(len(lv), 3 * depth4, self.limbs)
+        rt = np.ascontiguousarray(root, dtype=np.uint64).reshape(self.limbs)
+        ok = np.zeros(len(lv), dtype=np.uint8)
+        _check(lib.anemoi_merkle_verify_arity4_batch(self.field, _p64(lv), _p64(ix), _p64(pa) if pa.size else None,
+                                                     depth4, len(lv), _p64(rt), _p8(ok), self.device))
+        return ok.astype(bool)
 
     # ---- the reference's single-item surface (src/traits.rs:8-33)
     def permutation(self, state):

@@ -346,6 +346,24 @@ int merkle_levels_dev(int field, const void* d_leaves, unsigned depth, void* d_s
   return ANEMOI_OK;
 }
 
+// One level of arity-4 path verification: states[i] = the 4 children of item i's next node = its current
+// node at slot (index >> 2 level) & 3, the path's 3 siblings of that level in the other slots (child order).
+// Pure data movement, `quads` uint4 per element; one thread per (item, child, quad).
+__global__ void k_assemble4(const uint4* __restrict__ cur, const uint4* __restrict__ paths,
+                            const uint64_t* __restrict__ index, unsigned level, unsigned depth4, size_t n, int quads,
+                            uint4* __restrict__ states) {
+  const size_t t = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t per = size_t(4) * quads;
+  if (t >= n * per) return;
+  const size_t item = t / per;
+  const int child = int((t % per) / quads), q = int(t % quads);
+  const int pos = int((index[item] >> (2 * level)) & 3);
+  uint4 v;
+  if (child == pos) v = cur[item * quads + q];
+  else v = paths[((item * depth4 + level) * 3 + (child < pos ? child : child - 1)) * quads + q];
+  states[t] = v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -768,6 +786,89 @@ int anemoi_merkle_root_arity4(int field, const uint64_t* leaves, unsigned depth4
     }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(root, src, eb, hipMemcpyDeviceToHost));
+    return ANEMOI_OK;
+  });
+}
+
+int anemoi_merkle_tree_arity4(int field, const uint64_t* leaves, unsigned depth4, uint64_t* tree, int device) {
+  int rc = check_instance(field, 4);
+  if (rc) return rc;
+  if (!leaves || !tree || depth4 > 15) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field), nleaf = size_t(1) << (2 * depth4), total = ((nleaf << 2) - 1) / 3;
+  return for_devices(device == ANEMOI_ALL_DEVICES ? 0 : device, 1, [&](int dev, size_t, size_t) -> int {
+    DeviceGuard guard;
+    HIP_TRY(hipSetDevice(dev));
+    DevBuf dt;
+    int r = dt.alloc(total * eb);
+    if (r) return r;
+    HIP_TRY(hipMemcpy(dt.p, leaves, nleaf * eb, hipMemcpyHostToDevice));
+    PermConsts pc;
+    if ((r = get_consts(field, 4, &pc))) return r;
+    char* lvl = (char*)dt.p;
+    for (size_t n = nleaf / 4; n >= 1; n /= 4) {  // n nodes of the next level from 4 n of this one
+      char* next = lvl + 4 * n * eb;
+      HIP_TRY(anemoi::field_ops(field)->jive(4, 4, lvl, next, n, pc, nullptr));
+      lvl = next;
+      if (n == 1) break;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(tree, dt.p, total * eb, hipMemcpyDeviceToHost));
+    return ANEMOI_OK;
+  });
+}
+
+int anemoi_merkle_path_arity4(int field, const uint64_t* tree, unsigned depth4, size_t index, uint64_t* path) {
+  if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
+  if (!tree || (depth4 && !path) || depth4 > 15 || index >= (size_t(1) << (2 * depth4))) return ANEMOI_ERR_ARG;
+  const size_t L = anemoi::field_ops(field)->limbs64;
+  size_t off = 0;
+  for (unsigned l = 0; l < depth4; l++) {
+    const size_t node = index >> (2 * l), first = node & ~size_t(3);
+    int k = 0;
+    for (size_t c = 0; c < 4; c++)
+      if (first + c != node) memcpy(path + (size_t(l) * 3 + k++) * L, tree + (off + first + c) * L, L * 8);
+    off += size_t(1) << (2 * (depth4 - l));
+  }
+  return ANEMOI_OK;
+}
+
+int anemoi_merkle_verify_arity4_batch(int field, const uint64_t* leaves, const uint64_t* indices, const uint64_t* paths,
+                                      unsigned depth4, size_t n, const uint64_t* root, uint8_t* ok, int device) {
+  int rc = check_instance(field, 4);
+  if (rc) return rc;
+  if (depth4 > 31 || (n && (!leaves || !indices || !root || !ok || (depth4 && !paths)))) return ANEMOI_ERR_ARG;
+  if (n == 0) return ANEMOI_OK;
+  const size_t eb = elem_bytes(field);
+  const int quads = int(eb / 16);
+  return for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
+    if (!count) return ANEMOI_OK;
+    DeviceGuard guard;
+    HIP_TRY(hipSetDevice(dev));
+    DevBuf dcur, di, dp, dst;
+    int r = dcur.alloc(count * eb);
+    if (!r) r = di.alloc(count * 8);
+    if (!r) r = dp.alloc(count * depth4 * 3 * eb);
+    if (!r) r = dst.alloc(count * 4 * eb);
+    if (r) return r;
+    HIP_TRY(hipMemcpy(dcur.p, (const char*)leaves + first * eb, count * eb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(di.p, indices + first, count * 8, hipMemcpyHostToDevice));
+    if (depth4)
+      HIP_TRY(hipMemcpy(dp.p, (const char*)paths + first * depth4 * 3 * eb, count * depth4 * 3 * eb,
+                        hipMemcpyHostToDevice));
+    PermConsts pc;
+    if ((r = get_consts(field, 4, &pc))) return r;
+    const size_t threads = count * 4 * size_t(quads);
+    for (unsigned l = 0; l < depth4; l++) {
+      k_assemble4<<<unsigned((threads + 255) / 256), 256, 0, nullptr>>>((const uint4*)dcur.p, (const uint4*)dp.p,
+                                                                        (const uint64_t*)di.p, l, depth4, count, quads,
+                                                                        (uint4*)dst.p);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(anemoi::field_ops(field)->jive(4, 4, dst.p, dcur.p, count, pc, nullptr));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<uint64_t> got(count * (eb / 8));
+    HIP_TRY(hipMemcpy(got.data(), dcur.p, count * eb, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < count; i++) ok[first + i] = memcmp(&got[i * (eb / 8)], root, eb) == 0 ? 1 : 0;
     return ANEMOI_OK;
   });
 }

@@ -126,6 +126,17 @@ int anemoi_merkle_verify_batch(int field, const uint64_t *leaves, const uint64_t
 /* Arity-4 tree built with the 4-3 instance's Jive-4 compression (compress_k(.,4),
  * anemoi_4_3/hasher.rs:162-179): 4^depth4 leaf digests -> root (depth4 <= 15). */
 int anemoi_merkle_root_arity4(int field, const uint64_t *leaves, unsigned depth4, uint64_t *root, int device);
+/* The same tree with all levels retained: tree = level 0 (the 4^depth4 leaves) | level 1 | ... | root,
+ * (4^(depth4+1) - 1) / 3 elements. */
+int anemoi_merkle_tree_arity4(int field, const uint64_t *leaves, unsigned depth4, uint64_t *tree, int device);
+/* Authentication path of leaf `index` out of such a tree: per level (bottom-up) the 3 siblings of the
+ * node in child order, the node's own slot left out -- depth4 x 3 elements (host-side indexing only). */
+int anemoi_merkle_path_arity4(int field, const uint64_t *tree, unsigned depth4, size_t index, uint64_t *path);
+/* Batched verification on the GPU: item i rebuilds the root from leaves[i], indices[i] and its path
+ * (depth4 Jive-4 compressions) and ok[i] = (it equals `root`). */
+int anemoi_merkle_verify_arity4_batch(int field, const uint64_t *leaves, const uint64_t *indices,
+                                      const uint64_t *paths, unsigned depth4, size_t n, const uint64_t *root,
+                                      uint8_t *ok, int device);
 
 /* canonical little-endian integers (< p) <-> Montgomery elements.  from_montgomery's output is
  * exactly AnemoiDigest::to_bytes (src/<f>/anemoi_x/digest.rs:42-46) when viewed as bytes. */

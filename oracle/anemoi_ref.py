@@ -198,6 +198,31 @@ class Instance:
             level = [self.compress_k(level[4 * i: 4 * i + 4], 4)[0] for i in range(len(level) // 4)]
         return level[0]
 
+    def merkle_levels_arity4(self, leaves):
+        levels = [list(leaves)]
+        while len(levels[-1]) > 1:
+            cur = levels[-1]
+            levels.append([self.compress_k(cur[4 * i: 4 * i + 4], 4)[0] for i in range(len(cur) // 4)])
+        return levels
+
+    @staticmethod
+    def merkle_path_arity4(levels, index):
+        """per level (bottom-up) the node's 3 siblings in child order"""
+        path = []
+        for l in range(len(levels) - 1):
+            node = index >> (2 * l)
+            first = node & ~3
+            path += [levels[l][first + c] for c in range(4) if first + c != node]
+        return path
+
+    def merkle_climb_arity4(self, leaf, index, path):
+        cur = leaf
+        for l in range(len(path) // 3):
+            pos, sib = (index >> (2 * l)) & 3, path[3 * l: 3 * l + 3]
+            children = sib[:pos] + [cur] + sib[pos:]
+            cur = self.compress_k(children, 4)[0]
+        return cur
+
 
 # ---- generality the reference carries but no shipped instance uses (SURVEY.md §8 f4) -----------------
 def mul_by_generator_chain(x, g, p):

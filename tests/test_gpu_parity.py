@@ -211,6 +211,50 @@ def test_merkle_arity4(A, oracle, params, field):
         assert inst.decode(got) == [I.merkle_root_arity4(leaves_i)]
 
 
+@pytest.mark.parametrize("field", ["bn_254", "bls12_381", "pallas"])
+def test_merkle_arity4_tree_paths_verify(A, oracle, params, field):
+    """arity-4 tree with retained levels, authentication paths and batched verification vs the oracle"""
+    from anemoi_ref import Instance
+    I, fid = Instance(field, 4), FIELD_IDS.index(field)
+    inst = A.Anemoi(field, 4)
+    rng = random.Random(401 + fid)
+    for depth4 in (0, 1, 3):
+        n = 4 ** depth4
+        leaves_i = [rng.randrange(I.p) for _ in range(n)]
+        ref_levels = I.merkle_levels_arity4(leaves_i)
+        leaves = oracle.ints_to_mont(fid, leaves_i)
+        levels = inst.merkle_tree_arity4(leaves, depth4)
+        assert len(levels) == depth4 + 1
+        for got, exp in zip(levels, ref_levels):
+            assert inst.decode(got) == exp
+        assert (levels[-1][0] == inst.merkle_root_arity4(leaves, depth4)).all()
+        idx = sorted({0, n - 1, n // 3, (2 * n) // 3, rng.randrange(n)})
+        paths = np.stack([inst.merkle_path_arity4(levels, depth4, i) for i in idx]) if depth4 else \
+            np.zeros((len(idx), 0, inst.limbs), dtype=np.uint64)
+        for k, i in enumerate(idx):
+            exp_path = I.merkle_path_arity4(ref_levels, i)
+            assert inst.decode(paths[k]) == exp_path
+            assert I.merkle_climb_arity4(leaves_i[i], i, exp_path) == ref_levels[-1][0]
+        root = levels[-1][0]
+        sel = leaves[idx]
+        assert inst.merkle_verify_arity4_batch(sel, idx, paths, depth4, root).all()
+        if depth4:
+            bad = sel.copy()
+            bad[0, 0] ^= np.uint64(1)                      # tampered leaf
+            assert not inst.merkle_verify_arity4_batch(bad, idx, paths, depth4, root)[0]
+            wrong_idx = list(idx)
+            wrong_idx[-1] ^= 1                             # right leaf, wrong slot
+            assert not inst.merkle_verify_arity4_batch(sel, wrong_idx, paths, depth4, root)[-1]
+            badp = paths.copy()
+            badp[1, -1, 0] ^= np.uint64(2)                 # tampered top sibling
+            res = inst.merkle_verify_arity4_batch(sel, idx, badp, depth4, root)
+            assert not res[1] and res[0]
+    with pytest.raises(A.AnemoiError):
+        inst.merkle_path_arity4(levels, 3, 64)             # index out of range
+    with pytest.raises(A.AnemoiError):
+        A.Anemoi(field, 4).merkle_tree_arity4(leaves[:5], 1)
+
+
 def test_golden_extra_vectors(A, oracle):
     """Vectors minted by tools/mint_goldens.py from the Python big-int restatement for the cases the
     reference's tests leave unpinned (partial chunk, empty input, 10 KB messages, Merkle roots)."""
