@@ -64,6 +64,8 @@ _SIGS = {
     "anemoi_field_limbs": ([_int], _int),
     "anemoi_field_chunk_bytes": ([_int], _int),
     "anemoi_num_rounds": ([_int, _int], _int),
+    "anemoi_init": ([_int, _int, _int], _int),
+    "anemoi_release": ([_int], _int),
     "anemoi_permutation_batch": ([_int, _int, _u64p, _sz, _int], _int),
     "anemoi_sbox_layer_batch": ([_int, _int, _u64p, _sz, _int], _int),
     "anemoi_sbox_layer_dev": ([_int, _int, _vp, _sz, _vp], _int),

@@ -581,7 +581,12 @@ struct FieldOps {
   hipError_t (*generic_sponge)(int bytes, const void* d_src, size_t per_msg, size_t n, void* d_out, int rate,
                                GenericConsts gc, PermConsts pc, hipStream_t s);
   hipError_t (*exp_alpha)(int inverse, void* d_elems, size_t n, PermConsts pc, hipStream_t s);
+  // items one full wave of workgroups of a batch kernel processes on the current device (every CU at its
+  // resident-workgroup limit, from the occupancy API): the chunk quantum of the host-pointer pipeline
+  size_t (*wave_items)(int kind, int width, int num_cus);
 };
+
+enum KernelKind { kKindPermutation = 0, kKindJive = 1, kKindSponge = 2, kKindConvert = 3, kKindExpAlpha = 4 };
 
 const FieldOps* field_ops(int field);  // capi.hip
 
@@ -723,10 +728,36 @@ struct Launch {
     return hipGetLastError();
   }
 
+  template <class K>
+  static size_t resident_items(K kernel, size_t lds, int items_per_wg, int num_cus) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, lds) != hipSuccess || nb <= 0) {
+      (void)hipGetLastError();
+      nb = 12;  // 3 waves per SIMD: what the 13/14-limb kernels are built for
+    }
+    return size_t(nb) * size_t(num_cus) * size_t(items_per_wg);
+  }
+
+  static size_t wave_items(int kind, int width, int num_cus) {
+    switch (kind) {
+      case kKindPermutation:
+        return width == 2 ? resident_items(k_permutation<FIELD, 2, false>, lds_bytes<A, WIN, 2>(), kBlock, num_cus)
+                          : resident_items(k_permutation_pair<FIELD, false>, lds_bytes<A, WIN, 2>(), kPairStates, num_cus);
+      case kKindJive:
+        return width == 2 ? resident_items(k_jive<FIELD, 2, 2>, lds_bytes<A, WIN, 2>(), kBlock, num_cus)
+                          : resident_items(k_jive_pair<FIELD, 2>, lds_bytes<A, WIN, 2>(), kPairStates, num_cus);
+      case kKindSponge:
+        return width == 2 ? resident_items(k_sponge<FIELD, 2, true>, lds_bytes<A, WIN, 1>(), kBlock, num_cus)
+                          : resident_items(k_sponge_pair<FIELD, true>, lds_bytes<A, WIN, 2>(), kPairStates, num_cus);
+      case kKindExpAlpha: return resident_items(k_exp_alpha<FIELD, true>, lds_bytes<A, WIN, 1>(), kBlock, num_cus);
+      default: return resident_items(k_mont_convert<FIELD>, size_t(N) * 4 * kBlock, kBlock, num_cus);
+    }
+  }
+
   static const FieldOps* ops() {
     static const FieldOps o{F::L64,       F::kChunk,    F::kRounds21,        F::kRounds43, F::kG, F::kAlpha, F::kName,
                             host_consts,  permutation,  jive,                sponge,       mont_convert,
-                            merkle_climb, generic_permutation, generic_jive, generic_sponge, exp_alpha};
+                            merkle_climb, generic_permutation, generic_jive, generic_sponge, exp_alpha, wave_items};
     return &o;
   }
 };

@@ -1,11 +1,13 @@
 // capi.hip -- the C-ABI of libanemoi_mi355x.so (declared in include/anemoi_mi355x.h).
 //
-// Host side only: argument checks (the reference's assert!s -> error codes), the lazily created
-// per-device constant tables, H2D/D2H staging for the host-pointer entry points, contiguous-range
-// sharding over GPUs (no collective: items are independent) and the level-by-level
-// Merkle driver.  All arithmetic runs in the HIP kernels of anemoi_kernels.h; there is no CPU path.
+// Host side only: argument checks (the reference's assert!s -> error codes), the entry points, and the
+// Merkle drivers.  The machinery underneath -- per-device constant tables, lanes (streams + reusable
+// buffers), the chunked copy/compute pipeline and the contiguous-range sharding over GPUs (no
+// collective: items are independent) -- is runtime.h; the index arithmetic is
+// host_logic.h.  All field arithmetic runs in the HIP kernels of anemoi_kernels.h; there is no CPU path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -15,6 +17,8 @@
 
 #include "../../include/anemoi_mi355x.h"
 #include "anemoi_kernels.h"
+#include "host_logic.h"
+#include "runtime.h"
 
 namespace anemoi {
 const FieldOps *field_ops_0(), *field_ops_1(), *field_ops_2(), *field_ops_3(), *field_ops_4(), *field_ops_5(),
@@ -29,73 +33,15 @@ const FieldOps* field_ops(int field) {
 
 using anemoi::FieldOps;
 using anemoi::PermConsts;
+namespace host = anemoi::host;
+namespace rt = anemoi::rt;
+using rt::DeviceGuard;
+using rt::g_last_error;
+using rt::get_consts;
+using rt::Lane;
+using rt::LaneGuard;
 
 namespace {
-
-thread_local std::string g_last_error;
-
-int fail_hip(hipError_t e, const char* what) {
-  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
-  return ANEMOI_ERR_DEVICE;
-}
-
-#define HIP_TRY(expr)                                  \
-  do {                                                 \
-    hipError_t e_ = (expr);                            \
-    if (e_ != hipSuccess) return fail_hip(e_, #expr);  \
-  } while (0)
-
-constexpr int kMaxDevices = 64;
-
-struct DeviceCtx {
-  std::mutex mu;
-  bool ready[anemoi::kNumFields][2] = {};
-  PermConsts pc[anemoi::kNumFields][2] = {};
-};
-DeviceCtx g_ctx[kMaxDevices];
-
-// Constant tables for (current device, field, width); uploaded once.
-int get_consts(int field, int width, PermConsts* out) {
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= kMaxDevices) return ANEMOI_ERR_DEVICE;
-  DeviceCtx& c = g_ctx[dev];
-  const int wi = width == 2 ? 0 : 1;
-  std::lock_guard<std::mutex> lock(c.mu);
-  if (!c.ready[field][wi]) {
-    anemoi::HostConsts hc;
-    anemoi::field_ops(field)->host_consts(width, &hc);
-    // schedules go up as one 32-bit word per step (squarings | op << 8): scalar loads in the kernels
-    auto words = [](const std::vector<uint8_t>& pairs) {
-      std::vector<uint32_t> w(pairs.size() / 2);
-      for (size_t i = 0; i < w.size(); i++) w[i] = uint32_t(pairs[2 * i]) | (uint32_t(pairs[2 * i + 1]) << 8);
-      return w;
-    };
-    const std::vector<uint32_t> s3 = words(hc.sched), s5 = words(hc.sched5);
-    const std::vector<uint32_t>* parts[6] = {&hc.ark_c, &hc.ark_d, &s3, &s5, &hc.coop_c, &hc.coop_d};
-    size_t off[7] = {0};
-    for (int i = 0; i < 6; i++) off[i + 1] = off[i] + parts[i]->size() * sizeof(uint32_t);
-    char* blob = nullptr;
-    HIP_TRY(hipMalloc((void**)&blob, off[6]));
-    for (int i = 0; i < 6; i++)
-      HIP_TRY(hipMemcpy(blob + off[i], parts[i]->data(), parts[i]->size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    PermConsts pc;
-    pc.ark_c = (const uint32_t*)(blob + off[0]);
-    pc.ark_d = (const uint32_t*)(blob + off[1]);
-    pc.sched = (const uint32_t*)(blob + off[2]);
-    pc.steps = hc.steps;
-    pc.first = hc.first;
-    pc.sched5 = (const uint32_t*)(blob + off[3]);
-    pc.steps5 = hc.steps5;
-    pc.first5 = hc.first5;
-    pc.coop_c = (const uint32_t*)(blob + off[4]);
-    pc.coop_d = (const uint32_t*)(blob + off[5]);
-    c.pc[field][wi] = pc;
-    c.ready[field][wi] = true;
-  }
-  *out = c.pc[field][wi];
-  return ANEMOI_OK;
-}
 
 int check_instance(int field, int width) {
   if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
@@ -103,162 +49,35 @@ int check_instance(int field, int width) {
   return ANEMOI_OK;
 }
 
-// the reference's compress_k asserts (anemoi_2_1/hasher.rs:107; anemoi_4_3/hasher.rs:163-165)
-int check_k(int width, int k) {
-  if (width == 2) return k == 2 ? ANEMOI_OK : ANEMOI_ERR_ARG;
-  return (k == 2 || k == 4) ? ANEMOI_OK : ANEMOI_ERR_ARG;
-}
+int check_k(int width, int k) { return host::valid_k(width, k) ? ANEMOI_OK : ANEMOI_ERR_ARG; }
 
 size_t elem_bytes(int field) { return size_t(anemoi::field_ops(field)->limbs64) * 8; }
 
-struct DeviceGuard {  // restores the caller's current device
-  int prev = -1;
-  DeviceGuard() { (void)hipGetDevice(&prev); }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
-
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-  int alloc(size_t bytes) {
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-    if (e != hipSuccess) {
-      g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
-      return ANEMOI_ERR_ALLOC;
-    }
-    return ANEMOI_OK;
-  }
-};
-
-// Runs `body(first, count)` on one device, or on contiguous ranges over all devices (one host
-// thread per GPU).  body must be thread-safe and set its own device.
-template <class Body>
-int for_devices(int device, size_t n, Body body) {
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) {
-    g_last_error = "no HIP device";
-    return ANEMOI_ERR_DEVICE;
-  }
-  if (device != ANEMOI_ALL_DEVICES) {
-    if (device < 0 || device >= ndev || device >= kMaxDevices) {
-      g_last_error = "device ordinal out of range";
-      return ANEMOI_ERR_DEVICE;
-    }
-    return body(device, size_t(0), n);
-  }
-  if (ndev > kMaxDevices) ndev = kMaxDevices;
-  if (ndev == 1 || n < size_t(ndev)) return body(0, size_t(0), n);
-  std::vector<int> rc(ndev, ANEMOI_OK);
-  std::vector<std::string> err(ndev);
-  std::vector<std::thread> th;
-  for (int d = 0; d < ndev; d++) {
-    const size_t b = n * size_t(d) / size_t(ndev), e = n * size_t(d + 1) / size_t(ndev);
-    th.emplace_back([&, d, b, e] {
-      rc[d] = body(d, b, e - b);
-      if (rc[d] != ANEMOI_OK) err[d] = g_last_error;
-    });
-  }
-  for (auto& t : th) t.join();
-  for (int d = 0; d < ndev; d++)
-    if (rc[d] != ANEMOI_OK) {
-      g_last_error = err[d];
-      return rc[d];
-    }
-  return ANEMOI_OK;
+// Chunk quantum of a batch kernel on `dev`: items per full wave of workgroups (occupancy API; cached).
+size_t quantum_of(int field, int kind, int width, int dev) {
+  static std::mutex mu;
+  static size_t cache[anemoi::kNumFields][5][2] = {};
+  const int wi = width == 2 ? 0 : 1;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& q = cache[field][kind][wi];
+  if (!q) q = anemoi::field_ops(field)->wave_items(kind, width, rt::device_cus(dev));
+  return q;
 }
 
-// Generic host-pointer batch: copy `in_per_item` bytes per item in, run `launch`, copy out, all on the
-// device's default stream.  Cutting a batch into chunks on two streams (copy of chunk i+1 under the
-// kernel of chunk i) was measured and dropped: 2^20 BLS12-381 compressions from pageable memory took
-// 138.8 ms in 8 chunks against 130.2 ms unchunked (kernel 119.6 ms) -- every chunk ends in a partially
-// filled wave of workgroups on this ALU-bound kernel, which costs more than the ~10 ms of copies that
-// could be hidden.
-template <class LaunchFn>
-int host_batch(int device, size_t n, const void* in, size_t in_per_item, void* out, size_t out_per_item,
-               LaunchFn launch) {
-  if (n == 0) return ANEMOI_OK;
-  return for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
-    if (count == 0) return ANEMOI_OK;
-    DeviceGuard guard;
-    HIP_TRY(hipSetDevice(dev));
-    DevBuf din, dout;
-    int rc = din.alloc(count * in_per_item);
-    if (rc) return rc;
-    if (out != in) {
-      rc = dout.alloc(count * out_per_item);
-      if (rc) return rc;
-    }
-    void* o = out != in ? dout.p : din.p;
-    HIP_TRY(hipMemcpyAsync(din.p, (const char*)in + first * in_per_item, count * in_per_item, hipMemcpyHostToDevice,
-                           nullptr));
-    rc = launch(din.p, o, count, (hipStream_t) nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync((char*)out + first * out_per_item, o, count * out_per_item, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));
-    return ANEMOI_OK;
-  });
+// Borrows a lane on `dev` and runs body(lane); waits for the lane's streams if body failed.
+template <class Body>
+int with_lane(int dev, Body body) {
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(dev));
+  LaneGuard lg;
+  int rc = rt::acquire_lane(dev, &lg.ln);
+  if (rc) return rc;
+  rc = body(*lg.ln);
+  if (rc) rt::quiesce(*lg.ln);
+  return rc;
 }
 
 // ---- run-time instances (anemoi_generic.h) ---------------------------------------------------------
-
-// The matrix a hard-coded mds_layer arm applies to each half of the state, as small integers: the arm's
-// statements (src/traits.rs:136-279; mds_internal :307-323) applied to the unit vectors.
-bool builtin_mds(int c, uint64_t g, std::vector<uint64_t>* m) {
-  if (c < 1 || c > 6) return false;
-  m->assign(size_t(c) * c, 0);
-  for (int j = 0; j < c; j++) {
-    uint64_t s[6] = {0, 0, 0, 0, 0, 0}, o[6];
-    s[j] = 1;
-    switch (c) {
-      case 1: o[0] = s[0]; break;
-      case 2:
-        s[0] += g * s[1];
-        s[1] += g * s[0];
-        o[0] = s[0], o[1] = s[1];
-        break;
-      case 3: {
-        const uint64_t tmp = s[0] + g * s[2];
-        s[2] += s[1];
-        s[2] += g * s[0];
-        s[0] = tmp + s[2];
-        s[1] += tmp;
-        o[0] = s[0], o[1] = s[1], o[2] = s[2];
-        break;
-      }
-      case 4:
-        s[0] += s[1];
-        s[2] += s[3];
-        s[3] += g * s[0];
-        s[1] = g * (s[1] + s[2]);
-        s[0] += s[1];
-        s[2] += g * s[3];
-        s[1] += s[2];
-        s[3] += s[0];
-        for (int i = 0; i < 4; i++) o[i] = s[i];
-        break;
-      case 5: {
-        const uint64_t tot = s[0] + s[1] + s[2] + s[3] + s[4];
-        for (int i = 0; i < 5; i++)
-          o[i] = tot + s[(i + 3) % 5] + 2 * (s[(i + 2) % 5] + s[(i + 3) % 5] + 2 * s[(i + 4) % 5]);
-        break;
-      }
-      default: {
-        const uint64_t tot = s[0] + s[1] + s[2] + s[3] + s[4] + s[5];
-        for (int i = 0; i < 6; i++)
-          o[i] = tot + s[(i + 3) % 6] + s[(i + 5) % 6] +
-                 2 * (s[(i + 2) % 6] + s[(i + 3) % 6] + 2 * (s[(i + 4) % 6] + s[(i + 5) % 6]));
-        break;
-      }
-    }
-    for (int i = 0; i < c; i++) (*m)[size_t(i) * c + j] = o[i];
-  }
-  return true;
-}
 
 int check_generic(const anemoi_generic_instance* inst) {
   if (!inst) return ANEMOI_ERR_ARG;
@@ -269,25 +88,28 @@ int check_generic(const anemoi_generic_instance* inst) {
   return ANEMOI_OK;
 }
 
-// Uploads an instance's constants to the current device (stream-ordered on the default stream).
-int upload_generic(const anemoi_generic_instance* inst, DevBuf* blob, anemoi::GenericConsts* gc) {
+// Uploads an instance's constants into lane scratch buffer 0 (stream-ordered on the lane's kernel stream).
+int upload_generic(Lane& ln, const anemoi_generic_instance* inst, anemoi::GenericConsts* gc) {
   const FieldOps* ops = anemoi::field_ops(inst->field);
   const size_t eb = elem_bytes(inst->field), c = size_t(inst->num_columns);
   const size_t ab = size_t(inst->num_rounds) * c * eb, mb = c * c * eb;
-  int rc = blob->alloc(2 * ab + mb);
+  int rc = ln.scratch[0].reserve(2 * ab + mb);
   if (rc) return rc;
-  char* b = (char*)blob->p;
-  HIP_TRY(hipMemcpy(b, inst->ark_c, ab, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(b + ab, inst->ark_d, ab, hipMemcpyHostToDevice));
+  char* b = (char*)ln.scratch[0].p;
+  HIP_TRY(hipMemcpyAsync(b, inst->ark_c, ab, hipMemcpyHostToDevice, ln.s_k));
+  HIP_TRY(hipMemcpyAsync(b + ab, inst->ark_d, ab, hipMemcpyHostToDevice, ln.s_k));
+  std::vector<uint64_t> canon;  // must outlive the asynchronous copy below: synchronised before returning
   if (inst->mds) {
-    HIP_TRY(hipMemcpy(b + 2 * ab, inst->mds, mb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(b + 2 * ab, inst->mds, mb, hipMemcpyHostToDevice, ln.s_k));
   } else {
-    std::vector<uint64_t> small, canon(c * c * (eb / 8), 0);
-    if (!builtin_mds(inst->num_columns, uint64_t(ops->generator), &small)) return ANEMOI_ERR_ARG;
+    std::vector<uint64_t> small;
+    if (!host::builtin_mds(inst->num_columns, uint64_t(ops->generator), &small)) return ANEMOI_ERR_ARG;
+    canon.assign(c * c * (eb / 8), 0);
     for (size_t i = 0; i < c * c; i++) canon[i * (eb / 8)] = small[i];
-    HIP_TRY(hipMemcpy(b + 2 * ab, canon.data(), mb, hipMemcpyHostToDevice));
-    HIP_TRY(ops->mont_convert(1, b + 2 * ab, b + 2 * ab, c * c, nullptr));
+    HIP_TRY(hipMemcpyAsync(b + 2 * ab, canon.data(), mb, hipMemcpyHostToDevice, ln.s_k));
+    HIP_TRY(ops->mont_convert(1, b + 2 * ab, b + 2 * ab, c * c, ln.s_k));
   }
+  HIP_TRY(hipStreamSynchronize(ln.s_k));
   gc->ark_c = (const uint32_t*)b;
   gc->ark_d = (const uint32_t*)(b + ab);
   gc->mds = (const uint32_t*)(b + 2 * ab);
@@ -296,31 +118,35 @@ int upload_generic(const anemoi_generic_instance* inst, DevBuf* blob, anemoi::Ge
   return ANEMOI_OK;
 }
 
-// host-pointer batch over a run-time instance: constants are uploaded per device, then `launch`
+// host-pointer batch over a run-time instance: constants are uploaded per shard, then `launch`
 template <class LaunchFn>
 int generic_batch(const anemoi_generic_instance* inst, int device, size_t n, const void* in, size_t in_per_item,
                   void* out, size_t out_per_item, LaunchFn launch) {
   if (n == 0) return ANEMOI_OK;
-  return for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
+  return rt::for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
     if (count == 0) return ANEMOI_OK;
-    DeviceGuard guard;
-    HIP_TRY(hipSetDevice(dev));
-    DevBuf blob, din, dout;
-    anemoi::GenericConsts gc;
-    PermConsts pc;
-    int rc = upload_generic(inst, &blob, &gc);
-    if (!rc) rc = get_consts(inst->field, 2, &pc);  // exponent schedule of the field
-    if (!rc) rc = din.alloc(count * in_per_item);
-    if (!rc && out != in) rc = dout.alloc(count * out_per_item);
-    if (rc) return rc;
-    void* o = out != in ? dout.p : din.p;
-    HIP_TRY(hipMemcpy(din.p, (const char*)in + first * in_per_item, count * in_per_item, hipMemcpyHostToDevice));
-    HIP_TRY(launch(din.p, o, count, gc, pc));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy((char*)out + first * out_per_item, o, count * out_per_item, hipMemcpyDeviceToHost));
-    return ANEMOI_OK;
+    return with_lane(dev, [&](Lane& ln) -> int {
+      anemoi::GenericConsts gc;
+      PermConsts pc;
+      int rc = upload_generic(ln, inst, &gc);
+      if (!rc) rc = get_consts(inst->field, 2, &pc);  // exponent schedule of the field
+      if (!rc) rc = ln.scratch[1].reserve(count * in_per_item);
+      if (!rc && out != in) rc = ln.scratch[2].reserve(count * out_per_item);
+      if (rc) return rc;
+      void* di = ln.scratch[1].p;
+      void* o = out != in ? ln.scratch[2].p : di;
+      HIP_TRY(hipMemcpyAsync(di, (const char*)in + first * in_per_item, count * in_per_item, hipMemcpyHostToDevice,
+                             ln.s_k));
+      HIP_TRY(launch(di, o, count, gc, pc, ln.s_k));
+      HIP_TRY(hipMemcpyAsync((char*)out + first * out_per_item, o, count * out_per_item, hipMemcpyDeviceToHost,
+                             ln.s_k));
+      HIP_TRY(hipStreamSynchronize(ln.s_k));
+      return ANEMOI_OK;
+    });
   });
 }
+
+// ---- Merkle drivers ----------------------------------------------------------------------------------
 
 int merkle_levels_dev(int field, const void* d_leaves, unsigned depth, void* d_scratch, void* d_root,
                       hipStream_t s) {
@@ -346,6 +172,86 @@ int merkle_levels_dev(int field, const void* d_leaves, unsigned depth, void* d_s
   return ANEMOI_OK;
 }
 
+// A tree (arity 2^alog = 2 with the 2-1 instance's merge, or 4 with the 4-3 instance's Jive-4) over
+// arity^depth HOST leaves on the lane's device.  Level 1 is built by the chunked pipeline -- the copy of
+// the next chunk of leaves runs under the compression of this one, and the leaves never have to be
+// resident as a whole -- and stays on the device; the remaining levels follow on the lane's kernel
+// stream.  With `tree_host` every level l >= 1 is copied out to tree_host + (level_off[l] + part *
+// nodes_l) elements as soon as it is complete (on the copy-out stream, under the next levels); the root
+// is always written to `root_host`.
+struct TreeShape {
+  int field, alog;  // alog = log2(arity): 1 or 2
+  int width() const { return alog == 1 ? 2 : 4; }
+  int arity() const { return 1 << alog; }
+};
+
+int subtree_host(Lane& ln, TreeShape ts, const char* leaves, unsigned depth, char* root_host, char* tree_host,
+                 unsigned full_depth, size_t part) {
+  const FieldOps* ops = anemoi::field_ops(ts.field);
+  const size_t eb = elem_bytes(ts.field);
+  const int W = ts.width(), K = ts.arity();
+  if (depth == 0) {
+    memcpy(root_host, leaves, eb);
+    return ANEMOI_OK;
+  }
+  PermConsts pc;
+  int rc = get_consts(ts.field, W, &pc);
+  if (rc) return rc;
+  const size_t n1 = size_t(1) << (ts.alog * (depth - 1));  // nodes of level 1
+  // device levels 1 .. depth, back to back: n1 + n1/K + ... + 1 <= 2 n1 elements
+  size_t total = 0;
+  for (unsigned l = 1; l <= depth; l++) total += size_t(1) << (ts.alog * (depth - l));
+  if ((rc = ln.scratch[0].reserve(total * eb))) return rc;
+  char* lvl = (char*)ln.scratch[0].p;
+  const int dev = ln.dev;
+  rc = rt::pipeline(
+      ln, n1, leaves, size_t(K) * eb, nullptr, eb, quantum_of(ts.field, anemoi::kKindJive, W, dev),
+      [&](void* di, void* dout, size_t cnt, hipStream_t s) -> int {
+        HIP_TRY(ops->jive(W, K, di, dout, cnt, pc, s));
+        return ANEMOI_OK;
+      },
+      lvl);
+  if (rc) return rc;
+  // D2H of a finished level, on the copy-out stream behind the event recorded after that level's kernel
+  auto level_out = [&](unsigned l, const char* d_lvl, size_t nodes) -> int {
+    if (!tree_host) return ANEMOI_OK;
+    hipEvent_t e;
+    int r = ln.event(l, &e);
+    if (r) return r;
+    HIP_TRY(hipStreamWaitEvent(ln.s_out, e, 0));
+    const size_t off = ts.alog == 1 ? host::tree2_level_offset(full_depth, l) : host::tree4_level_offset(full_depth, l);
+    HIP_TRY(hipMemcpyAsync(tree_host + (off + part * nodes) * eb, d_lvl, nodes * eb, hipMemcpyDeviceToHost, ln.s_out));
+    return ANEMOI_OK;
+  };
+  auto mark = [&](unsigned l) -> int {  // level l's kernel(s) are queued on s_k: remember that point
+    if (!tree_host) return ANEMOI_OK;
+    hipEvent_t e;
+    int r = ln.event(l, &e);
+    if (r) return r;
+    HIP_TRY(hipEventRecord(e, ln.s_k));
+    return ANEMOI_OK;
+  };
+  if ((rc = mark(1))) return rc;
+  const char* src = lvl;
+  size_t n = n1;
+  for (unsigned l = 2; l <= depth; l++) {
+    char* dst = (char*)src + n * eb;
+    const size_t below = n;
+    n >>= ts.alog;
+    HIP_TRY(ops->jive(W, K, src, dst, n, pc, ln.s_k));
+    if ((rc = mark(l))) return rc;
+    // the copy of level l-1 is issued AFTER level l's kernel is queued: a D2H into pageable memory
+    // blocks the host until the data is there, and the GPU should not wait for the host meanwhile
+    if ((rc = level_out(l - 1, src, below))) return rc;
+    src = dst;
+  }
+  if ((rc = level_out(depth, src, 1))) return rc;
+  HIP_TRY(hipMemcpyAsync(root_host, src, eb, hipMemcpyDeviceToHost, ln.s_k));
+  HIP_TRY(hipStreamSynchronize(ln.s_k));
+  if (tree_host) HIP_TRY(hipStreamSynchronize(ln.s_out));
+  return ANEMOI_OK;
+}
+
 // One level of arity-4 path verification: states[i] = the 4 children of item i's next node = its current
 // node at slot (index >> 2 level) & 3, the path's 3 siblings of that level in the other slots (child order).
 // Pure data movement, `quads` uint4 per element; one thread per (item, child, quad).
@@ -364,11 +270,57 @@ __global__ void k_assemble4(const uint4* __restrict__ cur, const uint4* __restri
   states[t] = v;
 }
 
+// Root / retained tree over arity^depth host leaves, on one device or sharded into subtrees over all
+// devices (the only cross-GPU data: one subtree root per part, finished on the first device).
+int merkle_host(TreeShape ts, const uint64_t* leaves, unsigned depth, uint64_t* root, uint64_t* tree, int device) {
+  const size_t eb = elem_bytes(ts.field);
+  int ndev = 0, rc = rt::physical_devices(&ndev);
+  if (rc) return rc;
+  if (device != ANEMOI_ALL_DEVICES && (device < 0 || device >= ndev)) {
+    g_last_error = "device ordinal out of range";
+    return ANEMOI_ERR_DEVICE;
+  }
+  const size_t nleaf = size_t(1) << (ts.alog * depth);
+  if (tree && (const void*)tree != (const void*)leaves) memcpy(tree, leaves, nleaf * eb);  // level 0
+  const unsigned sub_lv = device == ANEMOI_ALL_DEVICES ? host::subtree_levels(depth, ts.alog, size_t(rt::shard_parts(ndev))) : 0;
+  std::vector<uint64_t> root_buf(eb / 8);
+  if (sub_lv == 0) {
+    const int dev = device == ANEMOI_ALL_DEVICES ? 0 : device;
+    rc = with_lane(dev, [&](Lane& ln) {
+      return subtree_host(ln, ts, (const char*)leaves, depth, (char*)root_buf.data(), (char*)tree, depth, 0);
+    });
+    if (rc) return rc;
+    if (root) memcpy(root, root_buf.data(), eb);
+    return ANEMOI_OK;
+  }
+  const size_t nsub = size_t(1) << (ts.alog * sub_lv);
+  const unsigned sub_depth = depth - sub_lv;
+  const size_t sub_leaves = size_t(1) << (ts.alog * sub_depth);
+  std::vector<uint64_t> tops(nsub * (eb / 8));
+  rc = rt::run_parts(int(nsub), ndev, nsub, [&](int part, int dev, size_t, size_t) -> int {
+    return with_lane(dev, [&](Lane& ln) {
+      return subtree_host(ln, ts, (const char*)leaves + size_t(part) * sub_leaves * eb, sub_depth,
+                          (char*)tops.data() + size_t(part) * eb, (char*)tree, depth, size_t(part));
+    });
+  });
+  if (rc) return rc;
+  // the top sub_lv levels over the nsub subtree roots, on the first device.  In a retained tree the
+  // subtree roots are level sub_depth, and levels sub_depth .. depth form exactly the layout of a tree
+  // over nsub leaves, so the top is built in place.
+  if (tree) {
+    const size_t off = ts.alog == 1 ? host::tree2_level_offset(depth, sub_depth) : host::tree4_level_offset(depth, sub_depth);
+    uint64_t* top = tree + off * (eb / 8);
+    memcpy(top, tops.data(), nsub * eb);  // (already there for sub_depth >= 1: level sub_depth was copied out)
+    return merkle_host(ts, top, sub_lv, root, top, 0);
+  }
+  return merkle_host(ts, tops.data(), sub_lv, root, nullptr, 0);
+}
+
 }  // namespace
 
 extern "C" {
 
-int anemoi_abi_version(void) { return 1; }
+int anemoi_abi_version(void) { return 2; }
 
 int anemoi_device_count(void) {
   int n = 0;
@@ -381,7 +333,7 @@ const char* anemoi_strerror(int code) {
     case ANEMOI_OK: return "ok";
     case ANEMOI_ERR_FIELD: return "unknown field id";
     case ANEMOI_ERR_WIDTH: return "state width must be 2 or 4";
-    case ANEMOI_ERR_ARG: return "invalid argument (null pointer, unsupported k, or size out of range)";
+    case ANEMOI_ERR_ARG: return "invalid argument (null pointer, unsupported k, overlapping buffers, or size out of range)";
     case ANEMOI_ERR_DEVICE: return "HIP device error";
     case ANEMOI_ERR_ALLOC: return "allocation failed";
     default: return "unknown error code";
@@ -419,13 +371,50 @@ int anemoi_num_rounds(int field, int width) {
   return width == 2 ? o->rounds21 : o->rounds43;
 }
 
+/* ---- lifecycle ---- */
+
+int anemoi_init(int device, int field, int width) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  int ndev = 0;
+  if ((rc = rt::physical_devices(&ndev))) return rc;
+  const int lo = device == ANEMOI_ALL_DEVICES ? 0 : device, hi = device == ANEMOI_ALL_DEVICES ? ndev : device + 1;
+  if (lo < 0 || hi > ndev) {
+    g_last_error = "device ordinal out of range";
+    return ANEMOI_ERR_DEVICE;
+  }
+  DeviceGuard guard;
+  for (int d = lo; d < hi; d++) {
+    HIP_TRY(hipSetDevice(d));
+    PermConsts pc;
+    if ((rc = get_consts(field, width, &pc))) return rc;
+    Lane* ln = nullptr;  // one warm lane: streams and events exist before the first real call
+    if ((rc = rt::acquire_lane(d, &ln))) return rc;
+    rt::release_lane(ln);
+  }
+  return ANEMOI_OK;
+}
+
+int anemoi_release(int device) {
+  int ndev = 0, rc = rt::physical_devices(&ndev);
+  if (rc) return rc;
+  const int lo = device == ANEMOI_ALL_DEVICES ? 0 : device, hi = device == ANEMOI_ALL_DEVICES ? ndev : device + 1;
+  if (lo < 0 || hi > ndev) {
+    g_last_error = "device ordinal out of range";
+    return ANEMOI_ERR_DEVICE;
+  }
+  for (int d = lo; d < hi; d++)
+    if ((rc = rt::release_device(d))) return rc;
+  return ANEMOI_OK;
+}
+
 /* ---- run-time instances ---- */
 
 int anemoi_generic_mds_matrix(int field, int num_columns, uint64_t* mds, int device) {
   const FieldOps* ops = anemoi::field_ops(field);
   if (!ops) return ANEMOI_ERR_FIELD;
   std::vector<uint64_t> small;
-  if (!mds || !builtin_mds(num_columns, uint64_t(ops->generator), &small)) return ANEMOI_ERR_ARG;
+  if (!mds || !host::builtin_mds(num_columns, uint64_t(ops->generator), &small)) return ANEMOI_ERR_ARG;
   const size_t L = size_t(ops->limbs64), cnt = small.size();
   std::vector<uint64_t> canon(cnt * L, 0);
   for (size_t i = 0; i < cnt; i++) canon[i * L] = small[i];
@@ -438,8 +427,8 @@ int anemoi_generic_permutation_batch(const anemoi_generic_instance* inst, uint64
   if (n && !states) return ANEMOI_ERR_ARG;
   const size_t per = elem_bytes(inst->field) * 2 * size_t(inst->num_columns);
   return generic_batch(inst, device, n, states, per, states, per,
-                       [&](void* i, void*, size_t cnt, anemoi::GenericConsts gc, PermConsts pc) {
-                         return anemoi::field_ops(inst->field)->generic_permutation(i, cnt, gc, pc, nullptr);
+                       [&](void* i, void*, size_t cnt, anemoi::GenericConsts gc, PermConsts pc, hipStream_t s) {
+                         return anemoi::field_ops(inst->field)->generic_permutation(i, cnt, gc, pc, s);
                        });
 }
 
@@ -449,13 +438,13 @@ int anemoi_generic_jive_compress_k_batch(const anemoi_generic_instance* inst, in
   if (rc) return rc;
   const int w = 2 * inst->num_columns;
   // the reference's asserts (anemoi_4_3/hasher.rs:163-165): k <= width, k | width, k even
-  if (k < 2 || k > w || w % k != 0 || k % 2 != 0) return ANEMOI_ERR_ARG;
+  if (!host::valid_generic_k(w, k)) return ANEMOI_ERR_ARG;
   if (n && (!in || !out)) return ANEMOI_ERR_ARG;
   if ((const void*)in == (void*)out) return ANEMOI_ERR_ARG;
   const size_t eb = elem_bytes(inst->field);
   return generic_batch(inst, device, n, in, eb * w, out, eb * (w / k),
-                       [&](void* i, void* o, size_t cnt, anemoi::GenericConsts gc, PermConsts pc) {
-                         return anemoi::field_ops(inst->field)->generic_jive(i, o, cnt, k, gc, pc, nullptr);
+                       [&](void* i, void* o, size_t cnt, anemoi::GenericConsts gc, PermConsts pc, hipStream_t s) {
+                         return anemoi::field_ops(inst->field)->generic_jive(i, o, cnt, k, gc, pc, s);
                        });
 }
 
@@ -468,9 +457,8 @@ static int generic_hash(const anemoi_generic_instance* inst, int rate, int bytes
   static const uint64_t dummy[2] = {0, 0};
   const size_t eb = elem_bytes(inst->field);
   return generic_batch(inst, device, n, src ? src : (const void*)dummy, bytes ? per_msg : eb * per_msg, out, eb,
-                       [&](void* i, void* o, size_t cnt, anemoi::GenericConsts gc, PermConsts pc) {
-                         return anemoi::field_ops(inst->field)->generic_sponge(bytes, i, per_msg, cnt, o, rate, gc, pc,
-                                                                               nullptr);
+                       [&](void* i, void* o, size_t cnt, anemoi::GenericConsts gc, PermConsts pc, hipStream_t s) {
+                         return anemoi::field_ops(inst->field)->generic_sponge(bytes, i, per_msg, cnt, o, rate, gc, pc, s);
                        });
 }
 
@@ -488,13 +476,15 @@ int anemoi_exp_alpha_batch(int field, int inverse, uint64_t* elems, size_t n, in
   if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
   if (n && !elems) return ANEMOI_ERR_ARG;
   const size_t eb = elem_bytes(field);
-  return host_batch(device, n, elems, eb, elems, eb, [&](void* i, void*, size_t cnt, hipStream_t s) -> int {
-    PermConsts pc;
-    int rc = get_consts(field, 2, &pc);
-    if (rc) return rc;
-    HIP_TRY(anemoi::field_ops(field)->exp_alpha(inverse ? 1 : 0, i, cnt, pc, s));
-    return ANEMOI_OK;
-  });
+  return rt::host_batch(
+      device, n, elems, eb, elems, eb, [&](int dev) { return quantum_of(field, anemoi::kKindExpAlpha, 2, dev); },
+      [&](void* i, void*, size_t cnt, hipStream_t s) -> int {
+        PermConsts pc;
+        int rc = get_consts(field, 2, &pc);
+        if (rc) return rc;
+        HIP_TRY(anemoi::field_ops(field)->exp_alpha(inverse ? 1 : 0, i, cnt, pc, s));
+        return ANEMOI_OK;
+      });
 }
 
 /* ---- device-pointer API ---- */
@@ -524,6 +514,10 @@ int anemoi_jive_compress_k_dev(int field, int width, int k, const void* d_in, vo
   if (rc) return rc;
   if ((rc = check_k(width, k))) return rc;
   if (n && (!d_in || !d_out)) return ANEMOI_ERR_ARG;
+  // the kernels read and write through __restrict__ pointers and a workgroup's outputs land where another
+  // workgroup's inputs are: overlapping buffers are a cross-workgroup race, so they are rejected
+  const size_t eb = elem_bytes(field);
+  if (host::ranges_overlap(d_in, n * width * eb, d_out, n * (width / k) * eb)) return ANEMOI_ERR_ARG;
   PermConsts pc;
   if ((rc = get_consts(field, width, &pc))) return rc;
   HIP_TRY(anemoi::field_ops(field)->jive(width, k, d_in, d_out, n, pc, (hipStream_t)stream));
@@ -613,9 +607,9 @@ int anemoi_permutation_batch(int field, int width, uint64_t* states, size_t n, i
   if (rc) return rc;
   if (n && !states) return ANEMOI_ERR_ARG;
   const size_t per = elem_bytes(field) * width;
-  return host_batch(device, n, states, per, states, per, [&](void* in, void*, size_t cnt, hipStream_t s) {
-    return anemoi_permutation_dev(field, width, in, cnt, s);
-  });
+  return rt::host_batch(
+      device, n, states, per, states, per, [&](int dev) { return quantum_of(field, anemoi::kKindPermutation, width, dev); },
+      [&](void* in, void*, size_t cnt, hipStream_t s) { return anemoi_permutation_dev(field, width, in, cnt, s); });
 }
 
 int anemoi_sbox_layer_batch(int field, int width, uint64_t* states, size_t n, int device) {
@@ -623,9 +617,9 @@ int anemoi_sbox_layer_batch(int field, int width, uint64_t* states, size_t n, in
   if (rc) return rc;
   if (n && !states) return ANEMOI_ERR_ARG;
   const size_t per = elem_bytes(field) * width;
-  return host_batch(device, n, states, per, states, per, [&](void* in, void*, size_t cnt, hipStream_t s) {
-    return anemoi_sbox_layer_dev(field, width, in, cnt, s);
-  });
+  return rt::host_batch(
+      device, n, states, per, states, per, [&](int dev) { return quantum_of(field, anemoi::kKindPermutation, width, dev); },
+      [&](void* in, void*, size_t cnt, hipStream_t s) { return anemoi_sbox_layer_dev(field, width, in, cnt, s); });
 }
 
 int anemoi_jive_compress_k_batch(int field, int width, int k, const uint64_t* in, uint64_t* out, size_t n,
@@ -634,11 +628,11 @@ int anemoi_jive_compress_k_batch(int field, int width, int k, const uint64_t* in
   if (rc) return rc;
   if ((rc = check_k(width, k))) return rc;
   if (n && (!in || !out)) return ANEMOI_ERR_ARG;
-  if ((const void*)in == (void*)out) return ANEMOI_ERR_ARG;
   const size_t eb = elem_bytes(field);
-  return host_batch(device, n, in, eb * width, out, eb * (width / k), [&](void* i, void* o, size_t cnt, hipStream_t s) {
-    return anemoi_jive_compress_k_dev(field, width, k, i, o, cnt, s);
-  });
+  if (host::ranges_overlap(in, n * width * eb, out, n * (width / k) * eb)) return ANEMOI_ERR_ARG;
+  return rt::host_batch(
+      device, n, in, eb * width, out, eb * (width / k), [&](int dev) { return quantum_of(field, anemoi::kKindJive, width, dev); },
+      [&](void* i, void* o, size_t cnt, hipStream_t s) { return anemoi_jive_compress_k_dev(field, width, k, i, o, cnt, s); });
 }
 
 int anemoi_jive_compress_batch(int field, int width, const uint64_t* in, uint64_t* out, size_t n, int device) {
@@ -656,10 +650,12 @@ int anemoi_hash_field_batch(int field, int width, const uint64_t* elems, size_t 
   if (n && (!out || (elems_per_msg && !elems))) return ANEMOI_ERR_ARG;
   const size_t eb = elem_bytes(field);
   static const uint64_t dummy[2] = {0, 0};
-  return host_batch(device, n, elems ? (const void*)elems : (const void*)dummy, eb * elems_per_msg, out, eb,
-                    [&](void* i, void* o, size_t cnt, hipStream_t s) {
-                      return anemoi_hash_field_dev(field, width, i, elems_per_msg, cnt, o, s);
-                    });
+  return rt::host_batch(
+      device, n, elems_per_msg ? (const void*)elems : (const void*)dummy, eb * elems_per_msg, out, eb,
+      [&](int dev) { return quantum_of(field, anemoi::kKindSponge, width, dev); },
+      [&](void* i, void* o, size_t cnt, hipStream_t s) {
+        return anemoi_hash_field_dev(field, width, i, elems_per_msg, cnt, o, s);
+      });
 }
 
 int anemoi_hash_bytes_batch(int field, int width, const uint8_t* msgs, size_t msg_len, size_t n, uint64_t* out,
@@ -668,61 +664,53 @@ int anemoi_hash_bytes_batch(int field, int width, const uint8_t* msgs, size_t ms
   if (rc) return rc;
   if (n && (!out || (msg_len && !msgs))) return ANEMOI_ERR_ARG;
   static const uint64_t dummy[2] = {0, 0};
-  return host_batch(device, n, msgs ? (const void*)msgs : (const void*)dummy, msg_len, out, elem_bytes(field),
-                    [&](void* i, void* o, size_t cnt, hipStream_t s) {
-                      return anemoi_hash_bytes_dev(field, width, i, msg_len, cnt, o, s);
-                    });
+  return rt::host_batch(
+      device, n, msg_len ? (const void*)msgs : (const void*)dummy, msg_len, out, elem_bytes(field),
+      [&](int dev) { return quantum_of(field, anemoi::kKindSponge, width, dev); },
+      [&](void* i, void* o, size_t cnt, hipStream_t s) {
+        return anemoi_hash_bytes_dev(field, width, i, msg_len, cnt, o, s);
+      });
 }
 
 int anemoi_to_montgomery(int field, const uint64_t* in, uint64_t* out, size_t count, int device) {
   if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
   if (count && (!in || !out)) return ANEMOI_ERR_ARG;
   const size_t eb = elem_bytes(field);
-  return host_batch(device, count, in, eb, out, eb, [&](void* i, void* o, size_t cnt, hipStream_t s) {
-    return anemoi_to_montgomery_dev(field, i, o, cnt, s);
-  });
+  return rt::host_batch(
+      device, count, in, eb, out, eb, [&](int dev) { return quantum_of(field, anemoi::kKindConvert, 2, dev); },
+      [&](void* i, void* o, size_t cnt, hipStream_t s) { return anemoi_to_montgomery_dev(field, i, o, cnt, s); });
 }
 
 int anemoi_from_montgomery(int field, const uint64_t* in, uint64_t* out, size_t count, int device) {
   if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
   if (count && (!in || !out)) return ANEMOI_ERR_ARG;
   const size_t eb = elem_bytes(field);
-  return host_batch(device, count, in, eb, out, eb, [&](void* i, void* o, size_t cnt, hipStream_t s) {
-    return anemoi_from_montgomery_dev(field, i, o, cnt, s);
-  });
+  return rt::host_batch(
+      device, count, in, eb, out, eb, [&](int dev) { return quantum_of(field, anemoi::kKindConvert, 2, dev); },
+      [&](void* i, void* o, size_t cnt, hipStream_t s) { return anemoi_from_montgomery_dev(field, i, o, cnt, s); });
+}
+
+/* ---- Merkle trees ---- */
+
+int anemoi_merkle_root(int field, const uint64_t* leaves, unsigned depth, uint64_t* root, int device) {
+  int rc = check_instance(field, 2);
+  if (rc) return rc;
+  if (!leaves || !root || depth > 30) return ANEMOI_ERR_ARG;
+  return merkle_host(TreeShape{field, 1}, leaves, depth, root, nullptr, device);
 }
 
 int anemoi_merkle_tree(int field, const uint64_t* leaves, unsigned depth, uint64_t* tree, int device) {
   int rc = check_instance(field, 2);
   if (rc) return rc;
   if (!leaves || !tree || depth > 30) return ANEMOI_ERR_ARG;
-  const size_t eb = elem_bytes(field), total = (size_t(2) << depth) - 1;
-  return for_devices(device == ANEMOI_ALL_DEVICES ? 0 : device, 1, [&](int dev, size_t, size_t) -> int {
-    DeviceGuard guard;
-    HIP_TRY(hipSetDevice(dev));
-    DevBuf dt;
-    int r = dt.alloc(total * eb);
-    if (r) return r;
-    HIP_TRY(hipMemcpy(dt.p, leaves, (size_t(1) << depth) * eb, hipMemcpyHostToDevice));
-    r = anemoi_merkle_tree_dev(field, dt.p, depth, dt.p, nullptr);
-    if (r) return r;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(tree, dt.p, total * eb, hipMemcpyDeviceToHost));
-    return ANEMOI_OK;
-  });
+  return merkle_host(TreeShape{field, 1}, leaves, depth, nullptr, tree, device);
 }
 
 /* host-side indexing only: the sibling of node (level l, position index >> l) for l = 0 .. depth-1 */
 int anemoi_merkle_path(int field, const uint64_t* tree, unsigned depth, size_t index, uint64_t* path) {
   if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
   if (!tree || (depth && !path) || depth > 30 || index >= (size_t(1) << depth)) return ANEMOI_ERR_ARG;
-  const size_t L = anemoi::field_ops(field)->limbs64;
-  size_t off = 0;
-  for (unsigned l = 0; l < depth; l++) {
-    const size_t pos = (index >> l) ^ 1;
-    memcpy(path + l * L, tree + (off + pos) * L, L * 8);
-    off += size_t(1) << (depth - l);
-  }
+  host::merkle_path2(tree, depth, index, size_t(anemoi::field_ops(field)->limbs64), path);
   return ANEMOI_OK;
 }
 
@@ -733,27 +721,28 @@ int anemoi_merkle_verify_batch(int field, const uint64_t* leaves, const uint64_t
   if (depth > 63 || (n && (!leaves || !indices || !root || !ok || (depth && !paths)))) return ANEMOI_ERR_ARG;
   if (n == 0) return ANEMOI_OK;
   const size_t eb = elem_bytes(field);
-  return for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
+  return rt::for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
     if (!count) return ANEMOI_OK;
-    DeviceGuard guard;
-    HIP_TRY(hipSetDevice(dev));
-    DevBuf dl, di, dp, dr;
-    int r = dl.alloc(count * eb);
-    if (!r) r = di.alloc(count * 8);
-    if (!r) r = dp.alloc(count * depth * eb);
-    if (!r) r = dr.alloc(count * eb);
-    if (r) return r;
-    HIP_TRY(hipMemcpy(dl.p, (const char*)leaves + first * eb, count * eb, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(di.p, indices + first, count * 8, hipMemcpyHostToDevice));
-    if (depth)
-      HIP_TRY(hipMemcpy(dp.p, (const char*)paths + first * depth * eb, count * depth * eb, hipMemcpyHostToDevice));
-    r = anemoi_merkle_climb_dev(field, dl.p, di.p, dp.p, depth, count, dr.p, nullptr);
-    if (r) return r;
-    HIP_TRY(hipDeviceSynchronize());
-    std::vector<uint64_t> got(count * (eb / 8));
-    HIP_TRY(hipMemcpy(got.data(), dr.p, count * eb, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < count; i++) ok[first + i] = memcmp(&got[i * (eb / 8)], root, eb) == 0 ? 1 : 0;
-    return ANEMOI_OK;
+    return with_lane(dev, [&](Lane& ln) -> int {
+      rt::Buf &dl = ln.scratch[0], &di = ln.scratch[1], &dp = ln.scratch[2], &dr = ln.scratch[3];
+      int r = dl.reserve(count * eb);
+      if (!r) r = di.reserve(count * 8);
+      if (!r) r = dp.reserve(count * depth * eb);
+      if (!r) r = dr.reserve(count * eb);
+      if (r) return r;
+      hipStream_t s = ln.s_k;
+      HIP_TRY(hipMemcpyAsync(dl.p, (const char*)leaves + first * eb, count * eb, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(di.p, indices + first, count * 8, hipMemcpyHostToDevice, s));
+      if (depth)
+        HIP_TRY(hipMemcpyAsync(dp.p, (const char*)paths + first * depth * eb, count * depth * eb, hipMemcpyHostToDevice, s));
+      r = anemoi_merkle_climb_dev(field, dl.p, di.p, dp.p, depth, count, dr.p, s);
+      if (r) return r;
+      std::vector<uint64_t> got(count * (eb / 8));
+      HIP_TRY(hipMemcpyAsync(got.data(), dr.p, count * eb, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      for (size_t i = 0; i < count; i++) ok[first + i] = memcmp(&got[i * (eb / 8)], root, eb) == 0 ? 1 : 0;
+      return ANEMOI_OK;
+    });
   });
 }
 
@@ -763,72 +752,20 @@ int anemoi_merkle_root_arity4(int field, const uint64_t* leaves, unsigned depth4
   int rc = check_instance(field, 4);
   if (rc) return rc;
   if (!leaves || !root || depth4 > 15) return ANEMOI_ERR_ARG;
-  const size_t eb = elem_bytes(field), nleaf = size_t(1) << (2 * depth4);
-  if (depth4 == 0) {
-    memcpy(root, leaves, eb);
-    return ANEMOI_OK;
-  }
-  return for_devices(device == ANEMOI_ALL_DEVICES ? 0 : device, 1, [&](int dev, size_t, size_t) -> int {
-    DeviceGuard guard;
-    HIP_TRY(hipSetDevice(dev));
-    DevBuf da, db;
-    int r = da.alloc(nleaf * eb);
-    if (!r) r = db.alloc(nleaf / 4 * eb);
-    if (r) return r;
-    HIP_TRY(hipMemcpy(da.p, leaves, nleaf * eb, hipMemcpyHostToDevice));
-    PermConsts pc;
-    if ((r = get_consts(field, 4, &pc))) return r;
-    void *src = da.p, *dst = db.p;
-    for (size_t n = nleaf / 4; n >= 1; n /= 4) {
-      HIP_TRY(anemoi::field_ops(field)->jive(4, 4, src, dst, n, pc, nullptr));
-      std::swap(src, dst);
-      if (n == 1) break;
-    }
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(root, src, eb, hipMemcpyDeviceToHost));
-    return ANEMOI_OK;
-  });
+  return merkle_host(TreeShape{field, 2}, leaves, depth4, root, nullptr, device);
 }
 
 int anemoi_merkle_tree_arity4(int field, const uint64_t* leaves, unsigned depth4, uint64_t* tree, int device) {
   int rc = check_instance(field, 4);
   if (rc) return rc;
   if (!leaves || !tree || depth4 > 15) return ANEMOI_ERR_ARG;
-  const size_t eb = elem_bytes(field), nleaf = size_t(1) << (2 * depth4), total = ((nleaf << 2) - 1) / 3;
-  return for_devices(device == ANEMOI_ALL_DEVICES ? 0 : device, 1, [&](int dev, size_t, size_t) -> int {
-    DeviceGuard guard;
-    HIP_TRY(hipSetDevice(dev));
-    DevBuf dt;
-    int r = dt.alloc(total * eb);
-    if (r) return r;
-    HIP_TRY(hipMemcpy(dt.p, leaves, nleaf * eb, hipMemcpyHostToDevice));
-    PermConsts pc;
-    if ((r = get_consts(field, 4, &pc))) return r;
-    char* lvl = (char*)dt.p;
-    for (size_t n = nleaf / 4; n >= 1; n /= 4) {  // n nodes of the next level from 4 n of this one
-      char* next = lvl + 4 * n * eb;
-      HIP_TRY(anemoi::field_ops(field)->jive(4, 4, lvl, next, n, pc, nullptr));
-      lvl = next;
-      if (n == 1) break;
-    }
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(tree, dt.p, total * eb, hipMemcpyDeviceToHost));
-    return ANEMOI_OK;
-  });
+  return merkle_host(TreeShape{field, 2}, leaves, depth4, nullptr, tree, device);
 }
 
 int anemoi_merkle_path_arity4(int field, const uint64_t* tree, unsigned depth4, size_t index, uint64_t* path) {
   if (!anemoi::field_ops(field)) return ANEMOI_ERR_FIELD;
   if (!tree || (depth4 && !path) || depth4 > 15 || index >= (size_t(1) << (2 * depth4))) return ANEMOI_ERR_ARG;
-  const size_t L = anemoi::field_ops(field)->limbs64;
-  size_t off = 0;
-  for (unsigned l = 0; l < depth4; l++) {
-    const size_t node = index >> (2 * l), first = node & ~size_t(3);
-    int k = 0;
-    for (size_t c = 0; c < 4; c++)
-      if (first + c != node) memcpy(path + (size_t(l) * 3 + k++) * L, tree + (off + first + c) * L, L * 8);
-    off += size_t(1) << (2 * (depth4 - l));
-  }
+  host::merkle_path4(tree, depth4, index, size_t(anemoi::field_ops(field)->limbs64), path);
   return ANEMOI_OK;
 }
 
@@ -840,99 +777,38 @@ int anemoi_merkle_verify_arity4_batch(int field, const uint64_t* leaves, const u
   if (n == 0) return ANEMOI_OK;
   const size_t eb = elem_bytes(field);
   const int quads = int(eb / 16);
-  return for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
+  return rt::for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
     if (!count) return ANEMOI_OK;
-    DeviceGuard guard;
-    HIP_TRY(hipSetDevice(dev));
-    DevBuf dcur, di, dp, dst;
-    int r = dcur.alloc(count * eb);
-    if (!r) r = di.alloc(count * 8);
-    if (!r) r = dp.alloc(count * depth4 * 3 * eb);
-    if (!r) r = dst.alloc(count * 4 * eb);
-    if (r) return r;
-    HIP_TRY(hipMemcpy(dcur.p, (const char*)leaves + first * eb, count * eb, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(di.p, indices + first, count * 8, hipMemcpyHostToDevice));
-    if (depth4)
-      HIP_TRY(hipMemcpy(dp.p, (const char*)paths + first * depth4 * 3 * eb, count * depth4 * 3 * eb,
-                        hipMemcpyHostToDevice));
-    PermConsts pc;
-    if ((r = get_consts(field, 4, &pc))) return r;
-    const size_t threads = count * 4 * size_t(quads);
-    for (unsigned l = 0; l < depth4; l++) {
-      k_assemble4<<<unsigned((threads + 255) / 256), 256, 0, nullptr>>>((const uint4*)dcur.p, (const uint4*)dp.p,
-                                                                        (const uint64_t*)di.p, l, depth4, count, quads,
-                                                                        (uint4*)dst.p);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(anemoi::field_ops(field)->jive(4, 4, dst.p, dcur.p, count, pc, nullptr));
-    }
-    HIP_TRY(hipDeviceSynchronize());
-    std::vector<uint64_t> got(count * (eb / 8));
-    HIP_TRY(hipMemcpy(got.data(), dcur.p, count * eb, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < count; i++) ok[first + i] = memcmp(&got[i * (eb / 8)], root, eb) == 0 ? 1 : 0;
-    return ANEMOI_OK;
-  });
-}
-
-int anemoi_merkle_root(int field, const uint64_t* leaves, unsigned depth, uint64_t* root, int device) {
-  int rc = check_instance(field, 2);
-  if (rc) return rc;
-  if (!leaves || !root || depth > 30) return ANEMOI_ERR_ARG;
-  const size_t eb = elem_bytes(field);
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) {
-    g_last_error = "no HIP device";
-    return ANEMOI_ERR_DEVICE;
-  }
-  // number of subtrees: a power of two, at most the GPU count and at most 2^depth
-  unsigned sub_log = 0;
-  if (device == ANEMOI_ALL_DEVICES)
-    while ((2u << sub_log) <= unsigned(ndev) && sub_log + 1 <= depth) sub_log++;
-  const unsigned nsub = 1u << sub_log, sub_depth = depth - sub_log;
-  std::vector<uint64_t> tops(size_t(nsub) * (eb / 8));
-  // each subtree is one "item" of the sharded loop: subtree i runs on device i (or `device`)
-  auto subtree = [&](int dev, size_t idx) -> int {
-    DeviceGuard guard;
-    HIP_TRY(hipSetDevice(dev));
-    const size_t nleaf = size_t(1) << sub_depth;
-    DevBuf dl, ds, dr;
-    int r = dl.alloc(nleaf * eb);
-    if (!r) r = ds.alloc(nleaf * eb);
-    if (!r) r = dr.alloc(eb);
-    if (r) return r;
-    HIP_TRY(hipMemcpy(dl.p, (const char*)leaves + idx * nleaf * eb, nleaf * eb, hipMemcpyHostToDevice));
-    r = merkle_levels_dev(field, dl.p, sub_depth, ds.p, dr.p, nullptr);
-    if (r) return r;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy((char*)tops.data() + idx * eb, dr.p, eb, hipMemcpyDeviceToHost));
-    return ANEMOI_OK;
-  };
-  if (nsub == 1) {
-    const int dev = device == ANEMOI_ALL_DEVICES ? 0 : device;
-    if (dev < 0 || dev >= ndev) {
-      g_last_error = "device ordinal out of range";
-      return ANEMOI_ERR_DEVICE;
-    }
-    if ((rc = subtree(dev, 0))) return rc;
-    memcpy(root, tops.data(), eb);
-    return ANEMOI_OK;
-  }
-  std::vector<int> rcs(nsub, ANEMOI_OK);
-  std::vector<std::string> errs(nsub);
-  std::vector<std::thread> th;
-  for (unsigned i = 0; i < nsub; i++)
-    th.emplace_back([&, i] {
-      rcs[i] = subtree(int(i), i);
-      if (rcs[i]) errs[i] = g_last_error;
+    return with_lane(dev, [&](Lane& ln) -> int {
+      rt::Buf &dcur = ln.scratch[0], &di = ln.scratch[1], &dp = ln.scratch[2], &dst = ln.scratch[3];
+      int r = dcur.reserve(count * eb);
+      if (!r) r = di.reserve(count * 8);
+      if (!r) r = dp.reserve(count * depth4 * 3 * eb);
+      if (!r) r = dst.reserve(count * 4 * eb);
+      if (r) return r;
+      hipStream_t s = ln.s_k;
+      HIP_TRY(hipMemcpyAsync(dcur.p, (const char*)leaves + first * eb, count * eb, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(di.p, indices + first, count * 8, hipMemcpyHostToDevice, s));
+      if (depth4)
+        HIP_TRY(hipMemcpyAsync(dp.p, (const char*)paths + first * depth4 * 3 * eb, count * depth4 * 3 * eb,
+                               hipMemcpyHostToDevice, s));
+      PermConsts pc;
+      if ((r = get_consts(field, 4, &pc))) return r;
+      const size_t threads = count * 4 * size_t(quads);
+      for (unsigned l = 0; l < depth4; l++) {
+        k_assemble4<<<unsigned((threads + 255) / 256), 256, 0, s>>>((const uint4*)dcur.p, (const uint4*)dp.p,
+                                                                     (const uint64_t*)di.p, l, depth4, count, quads,
+                                                                     (uint4*)dst.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(anemoi::field_ops(field)->jive(4, 4, dst.p, dcur.p, count, pc, s));
+      }
+      std::vector<uint64_t> got(count * (eb / 8));
+      HIP_TRY(hipMemcpyAsync(got.data(), dcur.p, count * eb, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      for (size_t i = 0; i < count; i++) ok[first + i] = memcmp(&got[i * (eb / 8)], root, eb) == 0 ? 1 : 0;
+      return ANEMOI_OK;
     });
-  for (auto& t : th) t.join();
-  for (unsigned i = 0; i < nsub; i++)
-    if (rcs[i]) {
-      g_last_error = errs[i];
-      return rcs[i];
-    }
-  // the only cross-GPU data: nsub subtree roots (<= 8 x 48 B), finished on device 0
-  return anemoi_merkle_root(field, tops.data(), sub_log, root, 0);
+  });
 }
 
 }  // extern "C"

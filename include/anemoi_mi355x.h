@@ -17,15 +17,30 @@
  * anemoi_to_montgomery / anemoi_from_montgomery.  Inputs must be fully reduced; outputs always are.
  *
  * OWNERSHIP / THREADING: the caller allocates and owns every buffer.  The library owns only its
- * per-device constant tables and scratch, created lazily under a mutex.  Every function is
- * re-entrant and may be called from any thread.  No function aborts or throws: errors are negative
- * return codes (the reference's `assert!` panics, e.g. hasher.rs:97,107, map to ANEMOI_ERR_ARG and
- * are re-raised as panics by the Rust shim).
+ * per-device constant tables and a pool of "lanes" (three non-blocking HIP streams, reusable device
+ * buffers and pinned staging each), created lazily under a mutex and kept until anemoi_release().
+ * Every function is re-entrant and may be called from any thread: each host-pointer call borrows its
+ * own lane, so concurrent callers run on their own streams and never on the NULL stream.  No function
+ * aborts or throws: errors are negative return codes (the reference's `assert!` panics, e.g.
+ * hasher.rs:97,107, map to ANEMOI_ERR_ARG and are re-raised as panics by the Rust shim).
  *
  * DEVICES: host-pointer functions take `device` = a HIP ordinal, or ANEMOI_ALL_DEVICES to split
- * the batch into contiguous ranges over every visible GPU (no collective: items are independent).
+ * the batch into contiguous ranges over every visible GPU, one host thread per GPU (no collective:
+ * items are independent).  Large batches are cut into chunks of whole "waves of workgroups" and the
+ * copy of chunk i + 1 runs under the kernel of chunk i, so the device footprint of a host-pointer call is
+ * three chunks (~100 MB), not the batch.  The Merkle functions shard into one subtree per GPU (binary:
+ * the largest power of two <= #GPUs; arity 4: the largest power of four) and finish the top levels on
+ * the first device -- the subtree roots are the only cross-GPU data.
  * `_dev` functions take pointers already resident in the current device's HBM plus a hipStream_t
- * (passed as void*, NULL = default stream), enqueue asynchronously and never synchronise.
+ * (passed as void*, NULL = default stream), enqueue asynchronously and do not synchronise -- except
+ * that the FIRST use of a (device, field, width) uploads that instance's constant tables with a blocking
+ * copy (not legal inside a stream capture): call anemoi_init() beforehand to get that out of the way.
+ * Input and output ranges of a `_dev` Jive call must not overlap (ANEMOI_ERR_ARG).
+ *
+ * ENVIRONMENT (diagnostics): ANEMOI_VIRTUAL_DEVICES=N makes ANEMOI_ALL_DEVICES shard into N ranges /
+ * subtrees mapped round-robin onto the physical GPUs (exercises the multi-GPU code on one GPU);
+ * ANEMOI_HOST_STAGING=direct|pinned selects how host buffers are copied; ANEMOI_COOP_MAX overrides the
+ * batch size below which Jive 2-to-1 takes the wave-cooperative latency kernel.
  */
 #ifndef ANEMOI_MI355X_H
 #define ANEMOI_MI355X_H
@@ -70,6 +85,15 @@ const char *anemoi_field_name(int field);
 int anemoi_field_limbs(int field);           /* u64 limbs per element */
 int anemoi_field_chunk_bytes(int field);     /* 31 or 47: bytes absorbed per element by hash() */
 int anemoi_num_rounds(int field, int width); /* NUM_HASH_ROUNDS, src/<f>/anemoi_x/mod.rs:31 */
+
+/* ---- lifecycle ------------------------------------------------------------------------------
+ * Optional.  anemoi_init uploads the constant tables of (field, width) to `device` (or to every device
+ * with ANEMOI_ALL_DEVICES) and creates one lane, so that later calls -- `_dev` calls in particular --
+ * neither allocate nor synchronise.  anemoi_release frees everything the library holds on `device`
+ * (constant tables, idle lanes with their streams and buffers); ANEMOI_ERR_ARG while other calls are in
+ * flight there.  The library can be used again afterwards (it re-initialises lazily). */
+int anemoi_init(int device, int field, int width);
+int anemoi_release(int device);
 
 /* ---- host-pointer batch API -------------------------------------------------------------- */
 

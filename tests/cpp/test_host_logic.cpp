@@ -1,0 +1,149 @@
+// test_host_logic.cpp -- the pure host side of the C-ABI (anemoi-rust_amd/csrc/host_logic.h) on the CPU,
+// built with -fsanitize=address,undefined by tools/sanitize_host.sh / tests/test_host_logic.py.
+// Covers: shard ranges (coverage, balance, no overflow), subtree planning, retained-tree layout and the
+// authentication-path indexing of both arities (against a brute-force tree of integers), overlap checks,
+// the chunk plan, the small-integer MDS matrices (against the reference's matrices, src/traits.rs:161-279)
+// and the compress_k argument rules (anemoi_2_1/hasher.rs:107, anemoi_4_3/hasher.rs:163-165).
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../anemoi-rust_amd/csrc/host_logic.h"
+
+using namespace anemoi::host;
+
+#define CHECK(c)                                                       \
+  do {                                                                 \
+    if (!(c)) {                                                        \
+      std::fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #c); \
+      std::exit(1);                                                    \
+    }                                                                  \
+  } while (0)
+
+static void test_shards() {
+  for (size_t n : {size_t(0), size_t(1), size_t(7), size_t(8), size_t(1000), size_t(1) << 24, (size_t(1) << 62) + 12345})
+    for (size_t parts : {size_t(1), size_t(2), size_t(3), size_t(8), size_t(64), size_t(1000)}) {
+      CHECK(shard_begin(n, 0, parts) == 0 && shard_begin(n, parts, parts) == n);
+      size_t lo = ~size_t(0), hi = 0;
+      for (size_t i = 0; i < parts; i++) {
+        const size_t b = shard_begin(n, i, parts), e = shard_begin(n, i + 1, parts);
+        CHECK(b <= e);
+        lo = e - b < lo ? e - b : lo;
+        hi = e - b > hi ? e - b : hi;
+      }
+      CHECK(hi - lo <= 1);  // balanced to +-1
+    }
+  // agrees with the plain formula where that does not overflow
+  for (size_t n = 0; n < 300; n++)
+    for (size_t parts = 1; parts < 20; parts++)
+      for (size_t i = 0; i <= parts; i++) CHECK(shard_begin(n, i, parts) == n * i / parts);
+}
+
+static void test_subtrees() {
+  CHECK(subtree_levels(24, 1, 8) == 3 && subtree_levels(24, 1, 7) == 2 && subtree_levels(24, 1, 1) == 0);
+  CHECK(subtree_levels(2, 1, 8) == 2 && subtree_levels(0, 1, 8) == 0 && subtree_levels(1, 1, 1000) == 1);
+  CHECK(subtree_levels(10, 2, 8) == 1 && subtree_levels(10, 2, 16) == 2 && subtree_levels(10, 2, 3) == 0);
+  CHECK(subtree_levels(1, 2, 64) == 1);
+}
+
+// brute-force trees over integers: node value = a hash-free stand-in (position-coded), only indices matter
+static void test_paths() {
+  for (unsigned depth = 0; depth <= 6; depth++) {
+    const size_t L = 3, total = tree2_total(depth);
+    CHECK(tree2_level_offset(depth, 0) == 0 && tree2_level_offset(depth, depth) == total - 1);
+    std::vector<uint64_t> tree(total * L);
+    for (unsigned l = 0; l <= depth; l++)
+      for (size_t j = 0; j < (size_t(1) << (depth - l)); j++)
+        for (size_t w = 0; w < L; w++) tree[(tree2_level_offset(depth, l) + j) * L + w] = (uint64_t(l) << 32) | (j << 4) | w;
+    for (size_t index = 0; index < (size_t(1) << depth); index++) {
+      std::vector<uint64_t> path(depth * L + 1, 0xdeadbeef);
+      merkle_path2(tree.data(), depth, index, L, path.data());
+      for (unsigned l = 0; l < depth; l++)
+        for (size_t w = 0; w < L; w++) CHECK(path[l * L + w] == ((uint64_t(l) << 32) | (((index >> l) ^ 1) << 4) | w));
+      CHECK(path[depth * L] == 0xdeadbeef);  // nothing written past the path
+    }
+  }
+  for (unsigned d4 = 0; d4 <= 3; d4++) {
+    const size_t L = 2, total = tree4_total(d4);
+    CHECK(tree4_level_offset(d4, d4) == total - 1);
+    std::vector<uint64_t> tree(total * L);
+    for (unsigned l = 0; l <= d4; l++)
+      for (size_t j = 0; j < (size_t(1) << (2 * (d4 - l))); j++)
+        for (size_t w = 0; w < L; w++) tree[(tree4_level_offset(d4, l) + j) * L + w] = (uint64_t(l) << 32) | (j << 4) | w;
+    for (size_t index = 0; index < (size_t(1) << (2 * d4)); index++) {
+      std::vector<uint64_t> path(d4 * 3 * L + 1, 0xdeadbeef);
+      merkle_path4(tree.data(), d4, index, L, path.data());
+      for (unsigned l = 0; l < d4; l++) {
+        const size_t node = index >> (2 * l);
+        int k = 0;
+        for (size_t c = 0; c < 4; c++) {
+          const size_t sib = (node & ~size_t(3)) + c;
+          if (sib == node) continue;
+          for (size_t w = 0; w < L; w++) CHECK(path[(l * 3 + k) * L + w] == ((uint64_t(l) << 32) | (sib << 4) | w));
+          k++;
+        }
+        CHECK(k == 3);
+      }
+      CHECK(path[d4 * 3 * L] == 0xdeadbeef);
+    }
+  }
+}
+
+static void test_overlap_and_chunks() {
+  char buf[256];
+  CHECK(ranges_overlap(buf, 64, buf, 64) && ranges_overlap(buf, 64, buf + 63, 1) && !ranges_overlap(buf, 64, buf + 64, 64));
+  CHECK(!ranges_overlap(buf, 0, buf, 64) && !ranges_overlap(buf + 10, 5, buf, 10) && ranges_overlap(buf + 10, 5, buf, 11));
+  // chunk plan: sizes are multiples of the quantum, cover n, and small batches are not cut
+  for (size_t q : {size_t(1), size_t(196608), size_t(262144)})
+    for (size_t n : {size_t(0), size_t(1), q, 2 * q - 1, 2 * q, 5 * q + 17, size_t(1) << 24})
+      for (size_t ipi : {size_t(32), size_t(96), size_t(10240)}) {
+        const ChunkPlan cp = plan_chunks(n, q, ipi, size_t(24) << 20);
+        if (n == 0) { CHECK(cp.chunks == 0); continue; }
+        CHECK(cp.chunks >= 1 && cp.chunk_items >= 1);
+        CHECK((cp.chunks - 1) * cp.chunk_items < n && cp.chunks * cp.chunk_items >= n);
+        if (n < 2 * q) CHECK(cp.chunks == 1 && cp.chunk_items == n);
+        else CHECK(cp.chunk_items % q == 0);
+      }
+  CHECK(plan_chunks(1000, 0, 8, 1 << 20).chunks >= 1);  // quantum 0 is treated as 1
+}
+
+static void test_mds_and_k() {
+  std::vector<uint64_t> m;
+  CHECK(!builtin_mds(0, 2, &m) && !builtin_mds(7, 2, &m));
+  CHECK(builtin_mds(1, 5, &m) && m == std::vector<uint64_t>({1}));
+  // NUM_COLUMNS = 2 (src/traits.rs:143-147 applied to unit vectors): [[1, g], [g, g^2 + 1]]
+  for (uint64_t g : {2, 3, 5, 7, 15, 22}) {
+    CHECK(builtin_mds(2, g, &m) && m == std::vector<uint64_t>({1, g, g, g * g + 1}));
+    // 3 columns, the reference's matrix (src/traits.rs:161-163): [[g+1, 1, g+1], [1, 1, g], [g, 1, 1]]
+    CHECK(builtin_mds(3, g, &m) && m == std::vector<uint64_t>({g + 1, 1, g + 1, 1, 1, g, g, 1, 1}));
+    // 4 columns (src/traits.rs:166-189)
+    CHECK(builtin_mds(4, g, &m));
+    // the arm's statements on a test vector == the matrix applied to it
+    uint64_t s[4] = {3, 5, 7, 11}, t[4] = {3, 5, 7, 11};
+    t[0] += t[1]; t[2] += t[3]; t[3] += g * t[0]; t[1] = g * (t[1] + t[2]); t[0] += t[1]; t[2] += g * t[3]; t[1] += t[2]; t[3] += t[0];
+    for (int i = 0; i < 4; i++) {
+      uint64_t acc = 0;
+      for (int j = 0; j < 4; j++) acc += m[i * 4 + j] * s[j];
+      CHECK(acc == t[i]);
+    }
+  }
+  // circulant arms: 5 columns circ(1, 2, 1+... ) -- every row is a rotation of the first
+  for (int c : {5, 6}) {
+    CHECK(builtin_mds(c, 2, &m));
+    for (int i = 1; i < c; i++)
+      for (int j = 0; j < c; j++) CHECK(m[i * c + j] == m[((j - i) % c + c) % c]);
+  }
+  CHECK(valid_k(2, 2) && !valid_k(2, 4) && !valid_k(2, 1) && valid_k(4, 2) && valid_k(4, 4) && !valid_k(4, 3) && !valid_k(4, 8));
+  CHECK(valid_generic_k(6, 2) && valid_generic_k(6, 6) && !valid_generic_k(6, 3) && !valid_generic_k(6, 4) && !valid_generic_k(6, 0));
+}
+
+int main() {
+  test_shards();
+  test_subtrees();
+  test_paths();
+  test_overlap_and_chunks();
+  test_mds_and_k();
+  std::printf("host logic ok\n");
+  return 0;
+}

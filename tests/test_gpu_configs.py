@@ -1,0 +1,331 @@
+"""BASELINE.json's configs AT FULL SIZE on the GPU against oracle-derived goldens, and the multi-device code
+paths on whatever GPUs are visible.
+
+tests/golden/cfg_full.json is minted by tools/mint_cfg_goldens.py: the pinned C oracle run over the seeded
+inputs of anemoi_amd/synth.py (the generator these tests and bench.py use), so every comparison below is
+GPU-vs-oracle, not GPU-vs-GPU.  The sharded entry points (`device=ANEMOI_ALL_DEVICES`) run twice: over
+the GPUs that are really there, and with ANEMOI_VIRTUAL_DEVICES=8 -- eight ranges / subtrees, one host
+thread each, mapped round-robin onto the physical devices -- so the partition, offset and gather
+arithmetic of config 4 and config 5 executes on a one-GPU box exactly as it would on eight.
+"""
+import hashlib
+import json
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from conftest import FIELD_IDS, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import anemoi_amd
+    assert anemoi_amd.device_count() >= 1
+    return anemoi_amd
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from anemoi_amd import synth as s
+    return s
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "cfg_full.json")) as f:
+        return json.load(f)
+
+
+class virtual_devices:
+    """ANEMOI_VIRTUAL_DEVICES=n for the duration of a with-block (the library reads it at every call)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.prev = os.environ.get("ANEMOI_VIRTUAL_DEVICES")
+        if self.n is None:
+            os.environ.pop("ANEMOI_VIRTUAL_DEVICES", None)
+        else:
+            os.environ["ANEMOI_VIRTUAL_DEVICES"] = str(self.n)
+
+    def __exit__(self, *exc):
+        if self.prev is None:
+            os.environ.pop("ANEMOI_VIRTUAL_DEVICES", None)
+        else:
+            os.environ["ANEMOI_VIRTUAL_DEVICES"] = self.prev
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def rows(hexes, limbs):
+    return np.frombuffer(bytes.fromhex("".join(hexes)), dtype=np.uint64).reshape(len(hexes), limbs)
+
+
+# ---------------------------------------------------------------- configs 2 and 4: Jive compress, BLS12-381
+
+def test_cfg2_2pow20_every_output_vs_oracle_golden(A, synth, golden):
+    g, cfg = golden["cfg2"], synth.CFG2
+    assert (g["seed"], g["n"]) == (cfg["seed"], cfg["n"])
+    st = synth.states(cfg["field"], 2, cfg["seed"], 0, cfg["n"])
+    out = A.Anemoi(cfg["field"], 2).compress_batch(st)[:, 0]
+    assert (out[::g["sample_stride"]] == rows(g["sample"], 6)).all()
+    assert sha(out) == g["sha256"]
+
+
+def test_cfg4_2pow24_sharded_over_all_devices(A, synth, golden):
+    """Config 4 whole: 2^24 compressions through device=ANEMOI_ALL_DEVICES, 8 contiguous shards (8 virtual
+    devices when fewer GPUs are visible).  SHA-256 of all 768 MiB of output, per-shard SHA-256 and a
+    4 096-item sample, all from the oracle."""
+    g, cfg = golden["cfg4"], synth.CFG4
+    n, shards = cfg["n"], cfg["shards"]
+    assert (g["seed"], g["n"], g["shards"]) == (cfg["seed"], n, shards)
+    st = synth.states(cfg["field"], 2, cfg["seed"], 0, n)
+    inst = A.Anemoi(cfg["field"], 2, device=A.ALL_DEVICES)
+    with virtual_devices(shards if A.device_count() < shards else None):
+        t0 = time.perf_counter()
+        out = inst.compress_batch(st)[:, 0]
+        dt = time.perf_counter() - t0
+    print("cfg4: 2^24 compressions, host pointers, %d device(s): %.3f s = %.2f M/s" % (A.device_count(), dt, n / dt / 1e6))
+    assert (out[::g["sample_stride"]] == rows(g["sample"], 6)).all()
+    per = n // shards
+    for i in range(shards):
+        assert sha(out[i * per:(i + 1) * per]) == g["shard_sha256"][i], "shard %d" % i
+    assert sha(out) == g["sha256"]
+    # the same shard alone on one device (what one rank of bench.py --gpus 8 processes)
+    one = A.Anemoi(cfg["field"], 2, device=0).compress_batch(st[3 * per:4 * per])[:, 0]
+    assert sha(one) == g["shard_sha256"][3]
+
+
+# ---------------------------------------------------------------- config 3: sponge, BN-254 4-3, 10 240-byte messages
+
+def test_cfg3_2pow16_distinct_messages_vs_oracle_golden(A, synth, golden):
+    g, cfg = golden["cfg3"], synth.CFG3
+    assert (g["seed"], g["n"], g["msg_len"]) == (cfg["seed"], cfg["n"], cfg["msg_len"])
+    msgs = synth.messages(cfg["seed"], 0, cfg["n"], cfg["msg_len"])
+    out = A.Anemoi(cfg["field"], 4).hash_batch(msgs)
+    assert (out[::g["sample_stride"]] == rows(g["sample"], 4)).all()
+    assert sha(out) == g["sha256"]
+
+
+# ---------------------------------------------------------------- config 5: depth-24 Jubjub Merkle tree
+
+def test_cfg5_depth24_tree_sharded_over_all_devices(A, synth, golden):
+    """Config 5 whole: 2^24 leaves, one depth-21 subtree per (virtual) device, top 3 levels on device 0.
+    Root, the 8 subtree roots, the depth-21 subtree alone, and -- through the retained-level builder --
+    the SHA-256 of every one of the 25 levels, all against the oracle."""
+    g, cfg = golden["cfg5"], synth.CFG5
+    depth, shards = cfg["depth"], cfg["shards"]
+    assert (g["seed"], g["depth"]) == (cfg["seed"], depth)
+    leaves = synth.elements(cfg["field"], cfg["seed"], 0, 1 << depth)
+    assert sha(leaves) == g["level_sha256"][0]
+    inst = A.Anemoi(cfg["field"], 2, device=A.ALL_DEVICES)
+    want_root = rows([g["root"]], 4)[0]
+    with virtual_devices(shards if A.device_count() < shards else None):
+        t0 = time.perf_counter()
+        root = inst.merkle_root(leaves, depth)
+        dt = time.perf_counter() - t0
+        print("cfg5: depth-24 root, host leaves, %d device(s): %.3f s" % (A.device_count(), dt))
+        assert (root == want_root).all()
+        levels = inst.merkle_tree(leaves, depth)
+    for l in range(depth + 1):
+        assert sha(levels[l]) == g["level_sha256"][l], "level %d" % l
+    assert (levels[depth - 3] == rows(g["subtree_roots_depth21"], 4)).all()
+    assert (levels[12] == rows(g["level12"], 4)).all()
+    del levels
+    # one GPU's share on one device, and the whole tree on one device
+    one = A.Anemoi(cfg["field"], 2, device=0)
+    sub = 1 << (depth - 3)
+    assert (one.merkle_root(leaves[5 * sub:6 * sub], depth - 3) == rows(g["subtree_roots_depth21"], 4)[5]).all()
+    assert (one.merkle_root(leaves, depth) == want_root).all()
+
+
+# ---------------------------------------------------------------- the sharded code paths, small and ragged
+
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_virtual_devices_equal_single_device_and_oracle(A, oracle, params, parts):
+    """for_devices / merkle_host with `parts` ranges: compress (2-1, 4-3 k=2 and k=4), sponge bytes and
+    elements, permutation in place, Montgomery conversion, path verification -- ragged n, n < parts, n = 0 --
+    bit-equal to the single-device result and to the oracle."""
+    rng = np.random.default_rng(parts)
+    fid = FIELD_IDS.index("jubjub")
+    one, many = A.Anemoi("jubjub", 2, device=0), A.Anemoi("jubjub", 2, device=A.ALL_DEVICES)
+    one4, many4 = A.Anemoi("bn_254", 4, device=0), A.Anemoi("bn_254", 4, device=A.ALL_DEVICES)
+    fid4 = FIELD_IDS.index("bn_254")
+    with virtual_devices(parts):
+        for n in (0, 1, parts - 1, parts, 5 * parts + 3, 1000, 2500):
+            st = rng.integers(0, 1 << 62, size=(n, 2, 4), dtype=np.uint64)
+            got = many.compress_batch(st)
+            assert (got == one.compress_batch(st)).all()
+            if n:
+                assert (got == oracle.compress_batch(fid, 2, st, threads=8)).all()
+            st4 = rng.integers(0, 1 << 60, size=(n, 4, 4), dtype=np.uint64)
+            for k in (2, 4):
+                got = many4.compress_k_batch(st4, k)
+                assert (got == one4.compress_k_batch(st4, k)).all()
+                if n:
+                    assert (got == oracle.compress_batch(fid4, 4, st4, k=k, threads=8)).all()
+            assert (many4.permutation_batch(st4) == one4.permutation_batch(st4)).all()
+            assert (A.to_montgomery("jubjub", st[:, 0] >> np.uint64(3), device=A.ALL_DEVICES)
+                    == A.to_montgomery("jubjub", st[:, 0] >> np.uint64(3), device=0)).all()
+        for n in (1, parts + 1, 77):
+            msgs = rng.integers(0, 256, size=(n, 100), dtype=np.uint8)
+            got = many4.hash_batch(msgs)
+            assert (got == oracle.hash_bytes_batch(fid4, 4, msgs, threads=8)).all()
+            el = rng.integers(0, 1 << 60, size=(n, 5, 4), dtype=np.uint64)
+            assert (many4.hash_field_batch(el) == oracle.hash_field_batch(fid4, 4, el, threads=8)).all()
+        # authentication paths: tree on one device, verification sharded
+        depth = 7
+        leaves = rng.integers(0, 1 << 62, size=(1 << depth, 4), dtype=np.uint64)
+        levels = one.merkle_tree(leaves, depth)
+        idx = np.arange(0, 1 << depth, 3, dtype=np.uint64)
+        paths = np.stack([one.merkle_path(levels, depth, int(i)) for i in idx])
+        lv = leaves[idx.astype(np.int64)].copy()
+        lv[1] ^= np.uint64(1)  # one tampered leaf
+        ok = many.merkle_verify_batch(lv, idx, paths, depth, levels[-1][0])
+        assert ok.tolist() == [i != 1 for i in range(len(idx))]
+
+
+@pytest.mark.parametrize("parts", [2, 3, 4, 8, 16])
+def test_virtual_devices_merkle_trees(A, oracle, parts):
+    """Subtree-per-device Merkle drivers: binary root and retained tree (depths around and below
+    log2(parts), so depth < levels of subtrees, depth not divisible ...) and the arity-4 forms, against
+    the oracle / the single-device tree."""
+    rng = np.random.default_rng(100 + parts)
+    fid = FIELD_IDS.index("pallas")
+    one, many = A.Anemoi("pallas", 2, device=0), A.Anemoi("pallas", 2, device=A.ALL_DEVICES)
+    one4, many4 = A.Anemoi("vesta", 4, device=0), A.Anemoi("vesta", 4, device=A.ALL_DEVICES)
+    with virtual_devices(parts):
+        for depth in (0, 1, 2, 3, 5, 8, 11):
+            leaves = rng.integers(0, 1 << 61, size=(1 << depth, 4), dtype=np.uint64)
+            want = oracle.merkle_root(fid, leaves, depth)
+            assert (many.merkle_root(leaves, depth) == want).all(), depth
+            tm, t1 = many.merkle_tree(leaves, depth), one.merkle_tree(leaves, depth)
+            assert len(tm) == depth + 1 and all((a == b).all() for a, b in zip(tm, t1)), depth
+            assert (tm[-1][0] == want).all()
+        for depth4 in (0, 1, 2, 4, 5):
+            leaves = rng.integers(0, 1 << 61, size=(1 << (2 * depth4), 4), dtype=np.uint64)
+            t1 = one4.merkle_tree_arity4(leaves, depth4)
+            tm = many4.merkle_tree_arity4(leaves, depth4)
+            assert all((a == b).all() for a, b in zip(tm, t1)), depth4
+            assert (many4.merkle_root_arity4(leaves, depth4) == t1[-1][0]).all()
+            if depth4:
+                # level 1 straight from the oracle: node = compress_k(4 children, 4)
+                fid4 = FIELD_IDS.index("vesta")
+                exp = oracle.compress_batch(fid4, 4, leaves.reshape(-1, 4, 4), k=4, threads=8)[:, 0]
+                assert (tm[1] == exp).all()
+
+
+@pytest.mark.skipif("__import__('anemoi_amd').device_count() < 2")
+def test_real_multi_gpu_all_devices(A, oracle):
+    """With >= 2 physical GPUs: ANEMOI_ALL_DEVICES without the virtual knob, compress / verify / Merkle root."""
+    rng = np.random.default_rng(7)
+    fid = FIELD_IDS.index("jubjub")
+    many = A.Anemoi("jubjub", 2, device=A.ALL_DEVICES)
+    with virtual_devices(None):
+        st = rng.integers(0, 1 << 62, size=(5003, 2, 4), dtype=np.uint64)
+        assert (many.compress_batch(st) == oracle.compress_batch(fid, 2, st, threads=8)).all()
+        leaves = rng.integers(0, 1 << 62, size=(1 << 12, 4), dtype=np.uint64)
+        assert (many.merkle_root(leaves, 12) == oracle.merkle_root(fid, leaves, 12)).all()
+        for d in range(A.device_count()):
+            assert (A.Anemoi("jubjub", 2, device=d).compress_batch(st[:100]) == many.compress_batch(st[:100])).all()
+
+
+# ---------------------------------------------------------------- chunked pipeline, staging modes, lifecycle
+
+@pytest.mark.parametrize("staging", ["pinned", "direct"])
+def test_chunked_pipeline_both_staging_modes(A, oracle, staging):
+    """Batches well beyond one chunk (so the 3-slot ring wraps) through both copy strategies, in place and
+    out of place; a strided sample against the oracle and all items against the small-batch path."""
+    prev = os.environ.get("ANEMOI_HOST_STAGING")
+    os.environ["ANEMOI_HOST_STAGING"] = staging
+    try:
+        fid = FIELD_IDS.index("jubjub")
+        inst = A.Anemoi("jubjub", 2)
+        rng = np.random.default_rng(11)
+        n = 9 * (1 << 18) + 12345  # ~2.4 M items, 151 MB in: >= 6 chunks
+        base = rng.integers(0, 1 << 62, size=(4096, 2, 4), dtype=np.uint64)
+        idx = rng.integers(0, 4096, size=n)
+        ref = oracle.compress_batch(fid, 2, base, threads=8)
+        out = inst.compress_batch(base[idx])
+        assert (out == ref[idx]).all()
+        base4 = rng.integers(0, 1 << 60, size=(512, 4, 4), dtype=np.uint64)
+        idx4 = rng.integers(0, 512, size=700001)
+        p1 = A.Anemoi("bn_254", 4).permutation_batch(base4[idx4])  # in place on the device
+        p0 = A.Anemoi("bn_254", 4).permutation_batch(base4)
+        assert (p1 == p0[idx4]).all()
+    finally:
+        if prev is None:
+            os.environ.pop("ANEMOI_HOST_STAGING", None)
+        else:
+            os.environ["ANEMOI_HOST_STAGING"] = prev
+
+
+def test_init_release_lifecycle(A, oracle):
+    fid = FIELD_IDS.index("vesta")
+    st = np.random.default_rng(5).integers(0, 1 << 61, size=(300, 2, 4), dtype=np.uint64)
+    want = oracle.compress_batch(fid, 2, st, threads=4)
+    assert A.lib.anemoi_init(0, fid, 2) == 0
+    assert A.lib.anemoi_init(A.ALL_DEVICES, fid, 4) == 0
+    assert A.lib.anemoi_init(0, 99, 2) == -1 and A.lib.anemoi_init(0, fid, 3) == -2
+    assert A.lib.anemoi_init(A.device_count(), fid, 2) == -4
+    assert (A.Anemoi("vesta", 2).compress_batch(st) == want).all()
+    assert A.lib.anemoi_release(0) == 0
+    assert A.lib.anemoi_release(0) == 0          # idempotent
+    assert (A.Anemoi("vesta", 2).compress_batch(st) == want).all()   # re-initialises lazily
+    assert A.lib.anemoi_release(A.ALL_DEVICES) == 0
+    assert A.lib.anemoi_release(A.device_count()) == -4
+
+
+def test_dev_jive_rejects_overlapping_buffers(A):
+    import torch
+    fid = FIELD_IDS.index("jubjub")
+    buf = torch.zeros(64 * 2 * 4 + 64 * 4, dtype=torch.int64, device="cuda:0")
+    p = buf.data_ptr()
+    s = torch.cuda.current_stream().cuda_stream
+    assert A.lib.anemoi_jive_compress_k_dev(fid, 2, 2, p, p, 64, s) == -3                  # same range
+    assert A.lib.anemoi_jive_compress_k_dev(fid, 2, 2, p, p + 64 * 2 * 4 * 8 - 32, 64, s) == -3   # out starts inside in
+    assert A.lib.anemoi_jive_compress_k_dev(fid, 2, 2, p, p + 64 * 2 * 4 * 8, 64, s) == 0  # adjacent: fine
+    torch.cuda.synchronize()
+
+
+def test_concurrent_callers_overlap_on_the_gpu(A, oracle):
+    """Every host-pointer call runs on its own lane (own non-blocking streams), so latency-bound calls
+    from several threads overlap on the device: 4 threads x 6 single-wave batches must take well under the
+    serial time (a NULL-stream / hipMalloc-per-call implementation serialises them)."""
+    fid = FIELD_IDS.index("bls12_381")
+    rng = np.random.default_rng(9)
+    sts = [rng.integers(0, 1 << 60, size=(48, 2, 6), dtype=np.uint64) for _ in range(4)]
+    want = [oracle.compress_batch(fid, 2, s, threads=4) for s in sts]
+    inst = A.Anemoi("bls12_381", 2)
+    for s in sts:
+        inst.compress_batch(s)  # warm: lanes, constants
+    reps = 6
+
+    def run(k, errs):
+        for _ in range(reps):
+            if not (inst.compress_batch(sts[k]) == want[k]).all():
+                errs.append(k)
+
+    errs = []
+    t0 = time.perf_counter()
+    for k in range(4):
+        run(k, errs)
+    serial = time.perf_counter() - t0
+    ths = [threading.Thread(target=run, args=(k, errs)) for k in range(4)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    conc = time.perf_counter() - t0
+    print("4 x %d latency-bound calls: serial %.1f ms, concurrent %.1f ms" % (reps, serial * 1e3, conc * 1e3))
+    assert not errs
+    assert conc < 0.6 * serial, (serial, conc)
