@@ -10,6 +10,7 @@ Elements cross this boundary as numpy uint64 rows of `limbs` little-endian words
 form (the arkworks in-memory form, see the header).  `to_montgomery` / `from_montgomery` convert
 canonical integers on the GPU.
 """
+from . import synth  # noqa: F401  (seeded workloads of the BASELINE configs)
 from ._lib import (ALL_DEVICES, FIELD_IDS, Anemoi, AnemoiError, GenericAnemoi, builtin_mds_matrix, exp_alpha_batch, device_count, field_id, lib, lib_path,
                    from_montgomery, to_montgomery, ints_to_limbs, limbs_to_ints)
 

@@ -202,6 +202,7 @@ int subtree_host(Lane& ln, TreeShape ts, const char* leaves, unsigned depth, cha
   size_t total = 0;
   for (unsigned l = 1; l <= depth; l++) total += size_t(1) << (ts.alog * (depth - l));
   if ((rc = ln.scratch[0].reserve(total * eb))) return rc;
+  if (tree_host && (rc = ln.pipeline_streams())) return rc;  // the level copies run on s_out
   char* lvl = (char*)ln.scratch[0].p;
   const int dev = ln.dev;
   rc = rt::pipeline(

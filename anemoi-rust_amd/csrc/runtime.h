@@ -93,7 +93,14 @@ struct Slot {
 // One in-flight host-pointer call on one device.
 struct Lane {
   int dev = -1;
-  hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+  // s_k: the lane's kernel stream; a call that fits one chunk runs entirely on it (copy-in, kernel,
+  // copy-out), so a small call occupies ONE stream -- HIP multiplexes streams onto a handful of hardware
+  // queues (GPU_MAX_HW_QUEUES, 4 by default) and kernels of two streams that share a queue serialise.
+  // The other three exist only once a call needed the multi-chunk pipeline: s_in / s_out for the copies,
+  // s_k2 so that consecutive chunks' kernels alternate between two streams and the next chunk's
+  // workgroups fill the CUs as the previous chunk drains (one stream would put a full barrier -- ~1.3 ms
+  // of ragged tail on a 19 ms chunk, measured -- between every two chunks).
+  hipStream_t s_k = nullptr, s_k2 = nullptr, s_in = nullptr, s_out = nullptr;
   Slot slot[kSlots];
   Buf scratch[kScratch];
   std::vector<hipEvent_t> events;  // extra events (one per tree level), created on demand
@@ -110,15 +117,19 @@ struct Lane {
 
   int create(int device) {
     dev = device;
-    HIP_TRY(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
     for (auto& s : slot) {
       s.p_in.pinned = s.p_out.pinned = true;
       HIP_TRY(hipEventCreateWithFlags(&s.e_in, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&s.e_k, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&s.e_out, hipEventDisableTiming));
     }
+    return ANEMOI_OK;
+  }
+  int pipeline_streams() {  // the three extra streams of the multi-chunk pipeline, on first need
+    if (!s_in) HIP_TRY(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+    if (!s_out) HIP_TRY(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+    if (!s_k2) HIP_TRY(hipStreamCreateWithFlags(&s_k2, hipStreamNonBlocking));
     return ANEMOI_OK;
   }
   void destroy() {
@@ -132,10 +143,10 @@ struct Lane {
     for (auto& b : scratch) b.release();
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     events.clear();
-    if (s_in) (void)hipStreamDestroy(s_in);
-    if (s_k) (void)hipStreamDestroy(s_k);
-    if (s_out) (void)hipStreamDestroy(s_out);
-    s_in = s_k = s_out = nullptr;
+    for (hipStream_t* st : {&s_k, &s_k2, &s_in, &s_out}) {
+      if (*st) (void)hipStreamDestroy(*st);
+      *st = nullptr;
+    }
   }
   void trim() {
     for (auto& s : slot) s.d_in.trim(), s.d_out.trim(), s.p_in.trim(), s.p_out.trim();
@@ -366,8 +377,30 @@ int pipeline(Lane& ln, size_t n, const char* in, size_t ipi, char* out, size_t o
              char* d_dst = nullptr) {
   const bool inplace = !d_dst && (const void*)in == (const void*)out;
   const host::ChunkPlan cp = host::plan_chunks(n, quantum, ipi, kChunkTargetBytes);
-  const int ns = cp.chunks > 1 ? kSlots : 1;
+  if (cp.chunks == 0) return ANEMOI_OK;
   const bool staged = staging_mode() == 1;
+  if (cp.chunks == 1) {
+    // one chunk: copy-in, kernel, copy-out in order on the lane's kernel stream
+    Slot& sl = ln.slot[0];
+    int rc = sl.d_in.reserve(n * ipi);
+    if (!rc && !inplace && !d_dst) rc = sl.d_out.reserve(n * opi);
+    if (!rc && staged) rc = sl.p_in.reserve(n * ipi);
+    if (!rc && staged && !d_dst) rc = sl.p_out.reserve(n * opi);
+    if (rc) return rc;
+    if (staged) memcpy(sl.p_in.p, in, n * ipi);
+    HIP_TRY(hipMemcpyAsync(sl.d_in.p, staged ? (const void*)sl.p_in.p : (const void*)in, n * ipi, hipMemcpyHostToDevice,
+                           ln.s_k));
+    void* dst = d_dst ? (void*)d_dst : (inplace ? sl.d_in.p : sl.d_out.p);
+    if ((rc = launch(sl.d_in.p, dst, n, ln.s_k))) return rc;
+    if (d_dst) return ANEMOI_OK;  // the caller continues on s_k
+    HIP_TRY(hipMemcpyAsync(staged ? sl.p_out.p : (void*)out, dst, n * opi, hipMemcpyDeviceToHost, ln.s_k));
+    HIP_TRY(hipStreamSynchronize(ln.s_k));
+    if (staged) memcpy(out, sl.p_out.p, n * opi);
+    return ANEMOI_OK;
+  }
+  const int ns = kSlots;
+  int rc0 = ln.pipeline_streams();
+  if (rc0) return rc0;
   for (int s = 0; s < ns; s++) {
     Slot& sl = ln.slot[s];
     int rc = sl.d_in.reserve(cp.chunk_items * ipi);
@@ -411,29 +444,27 @@ int pipeline(Lane& ln, size_t n, const char* in, size_t ipi, char* out, size_t o
       HIP_TRY(hipMemcpyAsync(sl.d_in.p, in + first_of(c) * ipi, bytes, hipMemcpyHostToDevice, ln.s_in));
     }
     HIP_TRY(hipEventRecord(sl.e_in, ln.s_in));
-    HIP_TRY(hipStreamWaitEvent(ln.s_k, sl.e_in, 0));
+    hipStream_t ks = (c & 1) ? ln.s_k2 : ln.s_k;  // chunks are independent: their kernels may overlap
+    HIP_TRY(hipStreamWaitEvent(ks, sl.e_in, 0));
     void* dst = d_dst ? (void*)(d_dst + first_of(c) * opi) : (inplace ? sl.d_in.p : sl.d_out.p);
-    if ((rc = launch(sl.d_in.p, dst, cnt, ln.s_k))) return rc;
-    HIP_TRY(hipEventRecord(sl.e_k, ln.s_k));
+    if ((rc = launch(sl.d_in.p, dst, cnt, ks))) return rc;
+    HIP_TRY(hipEventRecord(sl.e_k, ks));
     // the copy-out of the previous chunk is enqueued AFTER this chunk's copy-in and kernel: with
     // pageable memory a D2H call blocks the host until its kernel has finished
     if (c >= 1 && (rc = copy_out(c - 1))) return rc;
   }
-  if (cp.chunks) {
-    int rc = copy_out(cp.chunks - 1);
-    if (rc) return rc;
-    for (size_t c = cp.chunks > size_t(ns) ? cp.chunks - ns : 0; c < cp.chunks; c++)
-      if ((rc = drain(c))) return rc;
-  }
+  int rc = copy_out(cp.chunks - 1);
+  if (rc) return rc;
+  for (size_t c = cp.chunks > size_t(ns) ? cp.chunks - ns : 0; c < cp.chunks; c++)
+    if ((rc = drain(c))) return rc;  // (in d_dst mode this also joins both kernel streams on the host)
   return ANEMOI_OK;
 }
 
 // Waits for everything a failed or finished call left on the lane's streams, so that the lane can be
 // reused (and its buffers freed) safely.
 inline void quiesce(Lane& ln) {
-  (void)hipStreamSynchronize(ln.s_in);
-  (void)hipStreamSynchronize(ln.s_k);
-  (void)hipStreamSynchronize(ln.s_out);
+  for (hipStream_t st : {ln.s_in, ln.s_k, ln.s_k2, ln.s_out})
+    if (st) (void)hipStreamSynchronize(st);
 }
 
 // Host-pointer batch: shard over devices, borrow a lane per shard, run the pipeline.

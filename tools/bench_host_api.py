@@ -1,26 +1,89 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive rate of the host-pointer entry point (what the Rust shim calls):
-anemoi_jive_compress_batch on 2^20 BLS12-381 states in pageable host memory."""
+"""PCIe-inclusive rate of the host-pointer entry point (what the Rust shim calls) next to the
+device-resident rate of the same kernel: anemoi_jive_compress_batch on BLS12-381 Anemoi-2-1 states in
+pageable host memory, both staging modes (ANEMOI_HOST_STAGING=pinned|direct), 2^20 and 2^24 items, plus
+the concurrent-callers overlap of latency-bound calls.
+
+    python tools/bench_host_api.py [log2 sizes ...]      (default: 20 24)
+"""
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "anemoi-rust_amd"))
 import numpy as np
-import bench
+import torch
 import anemoi_amd as A
+from anemoi_amd import synth
 
-n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
-st = bench.synth_states(n, 5)
+sizes = [int(a) for a in sys.argv[1:]] or [20, 24]
+fid = A.field_id("bls12_381")
 inst = A.Anemoi("bls12_381", 2)
-inst.compress_batch(st[:1024])
-ts = []
-for _ in range(3):
-    t0 = time.perf_counter()
-    out = inst.compress_batch(st)
-    ts.append(time.perf_counter() - t0)
-t = sorted(ts)[1]
-print("host-pointer anemoi_jive_compress_batch: %d items in %.1f ms -> %.2f M compress/s (PCIe + alloc inclusive)"
-      % (n, t * 1e3, n / t / 1e6))
+inst.compress_batch(synth.states("bls12_381", 2, 1, 0, 4096))  # warm-up: constants, a lane
+
+
+def median(ts):
+    return sorted(ts)[len(ts) // 2]
+
+
+for lg in sizes:
+    n = 1 << lg
+    st = synth.states("bls12_381", 2, 0x5EED, 0, n)
+    out = np.empty((n, 1, 6), dtype=np.uint64)
+    # device-resident: inputs already in HBM, HIP events around the launch
+    d_in = torch.from_numpy(st.view(np.int64).reshape(-1)).to("cuda:0")
+    d_out = torch.empty(n * 6, dtype=torch.int64, device="cuda:0")
+    s = torch.cuda.current_stream()
+    res = []
+    for _ in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        assert A.lib.anemoi_jive_compress_k_dev(fid, 2, 2, d_in.data_ptr(), d_out.data_ptr(), n, s.cuda_stream) == 0
+        b.record(s)
+        torch.cuda.synchronize()
+        res.append(a.elapsed_time(b))
+    resident = median(res[1:])
+    want = d_out.cpu().numpy().view(np.uint64).reshape(n, 1, 6)
+    del d_in, d_out
+    torch.cuda.empty_cache()
+    print("2^%d items: device-resident kernel %.2f ms = %.2f M/s" % (lg, resident, n / resident / 1e3))
+    for mode in ("pinned", "direct"):
+        os.environ["ANEMOI_HOST_STAGING"] = mode
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            rc = A.lib.anemoi_jive_compress_batch(fid, 2, st.ctypes.data_as(A._lib._u64p), out.ctypes.data_as(A._lib._u64p), n, 0)
+            ts.append(time.perf_counter() - t0)
+            assert rc == 0
+        assert (out == want).all()
+        t = median(ts[1:]) * 1e3
+        print("  host-pointer, staging=%-6s: %.2f ms = %.2f M/s  -> %.3f x the resident rate (first call %.1f ms)"
+              % (mode, t, n / t / 1e3, resident / t, ts[0] * 1e3))
+    os.environ.pop("ANEMOI_HOST_STAGING", None)
+
+# concurrent callers: latency-bound calls (48 items = one wave-cooperative launch each) from 4 threads
+sts = [synth.states("bls12_381", 2, 77 + k, 0, 48) for k in range(4)]
+for s_ in sts:
+    inst.compress_batch(s_)
+reps = 8
+
+
+def run(k):
+    for _ in range(reps):
+        inst.compress_batch(sts[k])
+
+
+t0 = time.perf_counter()
+for k in range(4):
+    run(k)
+serial = time.perf_counter() - t0
+ths = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+t0 = time.perf_counter()
+for th in ths:
+    th.start()
+for th in ths:
+    th.join()
+conc = time.perf_counter() - t0
+print("4 threads x %d calls of 48 items: serial %.1f ms, concurrent %.1f ms (%.2f x)" % (reps, serial * 1e3, conc * 1e3, serial / conc))

@@ -1,25 +1,64 @@
 #!/usr/bin/env python3
-"""Merkle root timing (device-resident leaves) for a field/depth; run under different ANEMOI_COOP_MAX
-values to see what the wave-cooperative latency kernel buys on the top levels of the tree."""
-import ctypes, os, sys
+"""Merkle root timing for a field/depth on one GPU.
+
+  device-resident leaves, one stream, level by level   (anemoi_merkle_root_dev)
+  host leaves through anemoi_merkle_root with ANEMOI_VIRTUAL_DEVICES = 1, 2, 4, 8, 16: that many subtrees
+  built concurrently, each on its own lane (own streams), top levels afterwards -- shows what running
+  independent subtrees side by side buys on the latency-bound narrow levels.
+
+    python tools/bench_merkle.py <field name> <depth> [per-level]
+"""
+import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "anemoi-rust_amd"))
 import numpy as np, torch
-field, limbs, depth = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-lib = ctypes.CDLL(os.path.join(ROOT, "anemoi-rust_amd", "lib", "libanemoi_mi355x.so"))
-vp = ctypes.c_void_p
-lib.anemoi_merkle_root_dev.argtypes = [ctypes.c_int, vp, ctypes.c_uint, vp, vp, vp]
+import anemoi_amd as A
+from anemoi_amd import synth
+
+field, depth = sys.argv[1], int(sys.argv[2])
+fid, L = A.field_id(field), synth.limbs_of(field)
+leaves = synth.elements(field, 0xBEEF, 0, 1 << depth)
 dev = torch.device("cuda", 0)
-rng = np.random.default_rng(1)
-leaves = torch.from_numpy(rng.integers(0, 1 << 60, size=(1 << depth, limbs), dtype=np.uint64).view(np.int64).reshape(-1)).to(dev)
-scratch = torch.empty((1 << depth) * limbs, dtype=torch.int64, device=dev)
-root = torch.empty(limbs, dtype=torch.int64, device=dev)
+d_leaves = torch.from_numpy(leaves.view(np.int64).reshape(-1)).to(dev)
+scratch = torch.empty((1 << depth) * L, dtype=torch.int64, device=dev)
+d_root = torch.empty(L, dtype=torch.int64, device=dev)
 s = torch.cuda.current_stream()
-def run():
-    assert lib.anemoi_merkle_root_dev(field, leaves.data_ptr(), depth, scratch.data_ptr(), root.data_ptr(), s.cuda_stream) == 0
-run(); torch.cuda.synchronize()
+
+
+def run_dev():
+    assert A.lib.anemoi_merkle_root_dev(fid, d_leaves.data_ptr(), depth, scratch.data_ptr(), d_root.data_ptr(), s.cuda_stream) == 0
+
+
+run_dev(); torch.cuda.synchronize()
 ts = []
 for _ in range(3):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(s); run(); b.record(s); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
-print("field %d depth %d COOP_MAX=%s: %.2f ms  root[0]=%x" % (field, depth, os.environ.get("ANEMOI_COOP_MAX", "default"), sorted(ts)[1], root[0].item() & 0xffffffffffffffff))
+    a.record(s); run_dev(); b.record(s); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+root_dev = d_root.cpu().numpy().view(np.uint64)
+print("%s depth %d, device-resident, one stream (COOP_MAX=%s): %.2f ms" % (field, depth, os.environ.get("ANEMOI_COOP_MAX", "default"), sorted(ts)[1]))
+
+if len(sys.argv) > 3:  # per-level times: one launch per level, events around each
+    pc = []
+    src, n = d_leaves, 1 << depth
+    for l in range(depth):
+        n //= 2
+        dst = torch.empty(max(n, 1) * L, dtype=torch.int64, device=dev)
+        A.lib.anemoi_jive_compress_k_dev(fid, 2, 2, src.data_ptr(), dst.data_ptr(), n, s.cuda_stream)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s); A.lib.anemoi_jive_compress_k_dev(fid, 2, 2, src.data_ptr(), dst.data_ptr(), n, s.cuda_stream); b.record(s)
+        torch.cuda.synchronize()
+        pc.append((n, a.elapsed_time(b)))
+        src = dst
+    print("  per level (nodes: ms): " + "  ".join("%d: %.2f" % x for x in pc))
+    print("  sum of levels %.2f ms" % sum(t for _, t in pc))
+
+inst = A.Anemoi(field, 2, device=A.ALL_DEVICES)
+for parts in (1, 2, 4, 8, 16, 32):
+    os.environ["ANEMOI_VIRTUAL_DEVICES"] = str(parts)
+    inst.merkle_root(leaves, depth)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); r = inst.merkle_root(leaves, depth); ts.append(time.perf_counter() - t0)
+    assert (r == root_dev).all()
+    print("  host leaves, %2d concurrent subtrees: %.2f ms" % (parts, sorted(ts)[1] * 1e3))
