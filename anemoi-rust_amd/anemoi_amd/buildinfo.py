@@ -1,0 +1,57 @@
+"""Facts about the kernel sources next to this package: a content hash (so measured profiles can say which
+build they describe) and the multiply-add count of the headline kernel, read from the generated assembly.
+Pure Python, no device access; used by bench.py and tools/summarize_profiles.py."""
+import hashlib
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+CSRC = os.path.join(_ROOT, "csrc")
+
+
+def csrc_sha256():
+    """SHA-256 over the kernel / runtime sources and the Makefile (file names and contents, sorted)."""
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
+    for path in [os.path.join(CSRC, f) for f in files] + [os.path.join(_ROOT, "Makefile")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def bls12_381_limb_layout():
+    """v_mad_u64_u32 / instruction counts per squaring and multiplication of the shipped BLS12-381 layout
+    (the widest limbs listed in mont29_asm_gen.h = the default `Lane` layout)."""
+    hdr = open(os.path.join(CSRC, "mont29_asm_gen.h")).read()
+    best = None
+    for m in re.finditer(r"// bls12_381, (\d+)-bit limbs: (\d+) limbs; squaring (\d+) instructions \((\d+) v_mad_u64_u32, "
+                         r"\d+ split columns\), multiplication (\d+) \((\d+),", hdr):
+        best = {"limb_bits": int(m.group(1)), "limbs": int(m.group(2)), "sqr_instr": int(m.group(3)),
+                "sqr_mad": int(m.group(4)), "mul_instr": int(m.group(5)), "mul_mad": int(m.group(6))}
+    body = hdr[hdr.index("template <> struct AsmMont<0, %d>" % best["limb_bits"]):]
+    body = body[:body.index("};")]
+    sq, mu = body.split("static __forceinline__ void mul(")
+    wide = lambda s: sum(s.count(op) for op in ("v_lshrrev_b64", "v_lshl_add_u64", "v_mul_lo_u32"))
+    best["sqr_wide"], best["mul_wide"] = wide(sq), wide(mu)
+    return best
+
+
+def bls12_381_products_per_round():
+    """(squarings, multiplications) one round of k_jive<bls12_381> executes: the S-box's window schedule
+    (field_consts_gen.h, window ANEMOI_WIN = 3) + x^2 and the table + its two y^2 + the two settle() products."""
+    hdr = open(os.path.join(CSRC, "field_consts_gen.h")).read()
+    blk = hdr[hdr.index("struct FieldC<0>"):]
+    m = re.search(r"kW3Sched\[[^\]]*\]\s*=\s*\{([^}]*)\}", blk)
+    vals = [int(v, 0) for v in m.group(1).replace("\n", " ").split(",") if v.strip()]
+    pairs = list(zip(vals[0::2], vals[1::2]))
+    sq = sum(s for s, _ in pairs) + 1 + 2            # chain + x^2 + the two y^2
+    mu = sum(1 for _, op in pairs if op != 255 and op != 253) + 3 + 2   # chain + x^3, x^5, x^7 + 2 settles
+    return sq, mu
+
+
+def bls12_381_mad_per_compression():
+    lay = bls12_381_limb_layout()
+    sq, mu = bls12_381_products_per_round()
+    # 21 rounds + from_abi x 2 and to_abi x 1 (one Montgomery product each) + the final mds_layer's 2 settles
+    return 21 * (sq * lay["sqr_mad"] + mu * lay["mul_mad"]) + 5 * lay["mul_mad"]

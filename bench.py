@@ -4,10 +4,21 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path (anemoi_jive_compress_k_dev, k = 2) over one batch of 2^20
-synthetic states that are already resident in HBM (configs[1] of BASELINE.json).  With N > 1 every
-rank processes its own 2^20-state batch on its own GPU (weak scaling; items are independent, so
-there is no data-path collective -- SURVEY.md §8e); `value` = all ranks' items / max-over-ranks time.
+A "step" is one pass of the hot path (anemoi_jive_compress_k_dev, k = 2) over one batch of seeded
+synthetic states that are already resident in HBM.
+  N = 1  config 2 of BASELINE.json: 2^20 states (anemoi_amd/synth.py, seed 0xA9E30102).
+  N > 1  config 4: the 2^24-state batch (seed 0xA9E30104) cut into 8 contiguous shards of 2^21; rank r
+         processes shard r on its own GPU (N = 8 is config 4 whole; N = 2, 4 run its first N shards).  Items
+         are independent, so there is no data-path collective; torch.distributed
+         (RCCL) carries only the barrier and the max-over-ranks of the elapsed time.  Per-GPU work is
+         fixed for every N > 1 ("weak" scaling); N = 1 runs half of that (config 2), at the same rate.
+`value` = all ranks' items / max-over-ranks time.
+
+The line proves itself: after the timed loop every rank compares the outputs still sitting in its output
+buffer with the committed oracle goldens of that exact batch (tests/golden/cfg_full.json, minted by
+tools/mint_cfg_goldens.py from the CPU oracle): a strided sample item by item, and the SHA-256 of the
+whole buffer.  A mismatch exits non-zero and prints no line.  No oracle code runs in or before the timed
+region.
 
 PyTorch is plumbing only (device buffers, the stream, torch.distributed for the barrier/max); the
 work is done by libanemoi_mi355x.so through its C-ABI.
@@ -17,12 +28,19 @@ Also printed in the same JSON line:
                 launch duration measured with HIP events on the launch stream, against 8 TB/s HBM.
                 The path is VALU-bound by ~4 orders of magnitude (9 576 384-bit modmul per 144 B), so
                 this fraction is tiny by construction; `alu` carries the meaningful efficiency figure.
+                `traffic` comes from the committed rocprofv3 --pmc passes of this command and is
+                reported only when that profile was taken from the kernel sources being run
+                (csrc hash match); otherwise it is null and `traffic_stale` is true.
+  alu           v_mad_u64_u32 lane-operations per second / (1024 SIMDs x 16 lanes x clock).
   cpu_baseline  the pinned C oracle ("port": same algorithm, u64-limb CIOS like arkworks) timed on a
-                bounded sample on this box's host cores (rank 0, N = 1 only).
+                bounded sample on this box's host cores, all threads and one thread (rank 0, N = 1 only),
+                with the CPU model; plus a probe for a Rust toolchain that could time the reference itself.
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -35,20 +53,10 @@ import numpy as np
 import torch
 
 FIELD, WIDTH, LIMBS = "bls12_381", 2, 6
-BATCH_LOG2 = 20
 BYTES_PER_ITEM = 96 + 48          # 2 x 48 B in + 48 B out
 MODMUL_PER_ITEM = 9576            # 21 rounds x (454 + 2), reference chain
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E peak
-P_BLS12_381 = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
-
-
-def synth_states(n, seed):
-    """n x [2][6] u64 limbs, every element < p (any value < p is a valid Montgomery element)."""
-    rng = np.random.default_rng(seed)
-    st = rng.integers(0, 1 << 64, size=(n, WIDTH, LIMBS), dtype=np.uint64)
-    top = P_BLS12_381 >> 320
-    st[:, :, LIMBS - 1] = rng.integers(0, top, size=(n, WIDTH), dtype=np.uint64)  # top limb < p's top limb
-    return st
+SIMDS, LANES_PER_CLK, NOMINAL_GHZ = 1024, 16, 2.4
 
 
 def usable_cores():
@@ -64,8 +72,27 @@ def usable_cores():
     return max(1, min(cores, int(os.environ.get("ANEMOI_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(budget_s=12.0):
-    """Oracle timed on a bounded sample of the same workload (rank 0, N = 1)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def reference_toolchain_probe():
+    """Could the reference itself (Rust + arkworks from crates.io, no Cargo.lock) be timed here?  Probe only."""
+    cargo = shutil.which("cargo")
+    rustc = shutil.which("rustc")
+    vendored = any(os.path.isdir(os.path.expanduser(p)) for p in ("~/.cargo/registry", "/usr/local/cargo/registry"))
+    return {"cargo": cargo, "rustc": rustc, "vendored_registry": vendored,
+            "usable": bool(cargo and rustc and vendored)}
+
+
+def cpu_baseline(synth, budget_s=10.0):
+    """Oracle timed on a bounded sample of the same workload (rank 0, N = 1): all usable threads, then one."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
     path = None
@@ -75,18 +102,67 @@ def cpu_baseline(budget_s=12.0):
         path = None
     oracle = orc.Oracle(path)
     cores = usable_cores()
-    st = synth_states(64 * cores, 0xC0)
-    t0 = time.perf_counter()
-    oracle.compress_batch(0, WIDTH, st, threads=cores)
-    rate = len(st) / (time.perf_counter() - t0)
-    n = int(max(64 * cores, min(rate * budget_s, 1 << 20)))
-    st = synth_states(n, 0xC1)
-    t0 = time.perf_counter()
-    oracle.compress_batch(0, WIDTH, st, threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "compressions/s", "cores": cores, "kind": "port",
-            "sample": "%d BLS12-381 Anemoi-2-1 Jive compressions, C oracle (u64 CIOS Montgomery), %d threads, %.1f s"
-                      % (n, cores, dt)}
+
+    def timed(threads, budget):
+        st = synth.states(FIELD, WIDTH, 0xC0, 0, 64 * threads)
+        t0 = time.perf_counter()
+        oracle.compress_batch(0, WIDTH, st, threads=threads)
+        rate = len(st) / (time.perf_counter() - t0)
+        n = int(max(64 * threads, min(rate * budget, 1 << 20)))
+        st = synth.states(FIELD, WIDTH, 0xC1, 0, n)
+        t0 = time.perf_counter()
+        oracle.compress_batch(0, WIDTH, st, threads=threads)
+        dt = time.perf_counter() - t0
+        return n / dt, n, dt
+
+    rate, n, dt = timed(cores, budget_s)
+    rate1, n1, dt1 = timed(1, budget_s / 3)
+    return {"value": rate, "unit": "compressions/s", "cores": cores, "kind": "port",
+            "single_thread": rate1, "cpu_model": cpu_model(), "compiler": orc.compiler_description(),
+            "sample": "%d BLS12-381 Anemoi-2-1 Jive compressions on %d threads in %.1f s; %d on 1 thread in %.1f s; "
+                      "C oracle (u64 CIOS Montgomery, the arkworks algorithm restated), not the reference binary"
+                      % (n, cores, dt, n1, dt1),
+            "reference_binary": reference_toolchain_probe()}
+
+
+def rank_shard(rank, world, batch_log2=None):
+    """(config name, config, first item, item count) of `rank` out of `world`: config 2 alone on one GPU,
+    contiguous 2^21-item shards of config 4 otherwise."""
+    from anemoi_amd import synth
+    cfg_name, cfg = ("cfg2", synth.CFG2) if world == 1 else ("cfg4", synth.CFG4)
+    lg = batch_log2 if batch_log2 is not None else (20 if world == 1 else 21)
+    n = 1 << lg
+    first = rank * n
+    if first + n > cfg["n"]:
+        raise SystemExit("rank %d: items [%d, %d) are beyond %s's %d" % (rank, first, first + n, cfg_name, cfg["n"]))
+    return cfg_name, cfg, first, n
+
+
+def verify_against_golden(out_host, golden, first, n, check_sha=True):
+    """out_host: (n, 6) uint64 outputs of items [first, first + n) of the golden's batch.  Returns (number of
+    sampled items compared, whether the whole-buffer SHA-256 was checked and equal, error text or None)."""
+    stride = golden["sample_stride"]
+    checked = 0
+    for j, hx in enumerate(golden["sample"]):
+        idx = j * stride
+        if first <= idx < first + n:
+            want = np.frombuffer(bytes.fromhex(hx), dtype=np.uint64)
+            if not (out_host[idx - first] == want).all():
+                return checked, False, "output of item %d differs from the oracle golden" % idx
+            checked += 1
+    sha_ok = None
+    digest = hashlib.sha256(np.ascontiguousarray(out_host).tobytes()).hexdigest() if check_sha else None
+    if not check_sha:
+        pass
+    elif first == 0 and n == golden["n"]:
+        sha_ok = digest == golden["sha256"]
+    elif "shard_sha256" in golden and n * golden["shards"] == golden["n"] and first % n == 0:
+        sha_ok = digest == golden["shard_sha256"][first // n]
+    if sha_ok is False:
+        return checked, False, "SHA-256 of the output buffer differs from the oracle golden"
+    if checked == 0:
+        return 0, False, "no golden sample falls inside this rank's items; nothing verified"
+    return checked, bool(sha_ok), None
 
 
 def main():
@@ -94,7 +170,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-log2", type=int, default=BATCH_LOG2)
+    ap.add_argument("--batch-log2", type=int, default=None,
+                    help="items per GPU (default: 20 for N = 1 = config 2, 21 for N > 1 = config 4's shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -104,7 +181,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     # one process per GPU; ANEMOI_BENCH_BACKEND=gloo lets the N > 1 path be rehearsed on a box with
-    # fewer GPUs than ranks (ranks then share devices round-robin; timing is meaningless there)
+    # fewer GPUs than ranks (ranks then share devices round-robin; timing is meaningless there).
+    # There is no silent fallback: if RCCL fails the run fails.
     backend = os.environ.get("ANEMOI_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     local_rank = local_rank % max(ndev, 1) if backend == "gloo" else local_rank
@@ -115,25 +193,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            try:  # create the RCCL communicator now, outside the timed region
-                dist.barrier()
-            except Exception as e:  # the data path has no collective: the control plane may fall back to gloo
-                sys.stderr.write("rank %d: RCCL barrier failed (%s); control plane falls back to gloo\n" % (rank, e))
-                dist.destroy_process_group()
-                backend = "gloo"
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()  # create the RCCL communicator now, outside the timed region
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import anemoi_amd as A  # after torch: binds to the same HIP runtime
+    from anemoi_amd import buildinfo, synth
     from anemoi_amd.shard import max_over_ranks
     fid = A.field_id(FIELD)
-    n = 1 << args.batch_log2
+    cfg_name, cfg, first, n = rank_shard(rank, world, args.batch_log2)   # contiguous shards of the config's batch
+    lg = n.bit_length() - 1
     dev = torch.device("cuda", local_rank)
-    host = synth_states(n, 0xA9E30102 + rank)
+    host = synth.states(FIELD, WIDTH, cfg["seed"], first, n)
     d_in = torch.from_numpy(host.view(np.int64).reshape(-1)).to(dev)
-    d_out = torch.empty(n * LIMBS, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(n * LIMBS, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
+    rc = A.lib.anemoi_init(local_rank, fid, WIDTH)   # constant tables up front: the steps only launch
+    if rc != 0:
+        raise A.AnemoiError(rc, A.lib.anemoi_last_error().decode())
 
     def step():
         rc = A.lib.anemoi_jive_compress_k_dev(fid, WIDTH, 2, d_in.data_ptr(), d_out.data_ptr(), n, stream.cuda_stream)
@@ -148,6 +225,8 @@ def main():
     for _ in range(max(args.warmup, 0)):
         step()
     barrier()
+    d_out.zero_()                          # the check below must see what the TIMED steps wrote
+    torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in evs:
@@ -161,52 +240,75 @@ def main():
     elapsed = max_over_ranks(elapsed, dist, dev if backend == "nccl" else None)
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
 
-    # spot-check the timed output against the C-ABI's own single-item path is the tests' job; here only
-    # make sure the kernel wrote something other than the input pattern
-    assert int(torch.count_nonzero(d_out[: 6 * 64]).item()) > 0
+    # ---- the timed output against the oracle goldens of this exact batch (every rank checks its shard)
+    with open(os.path.join(ROOT, "tests", "golden", "cfg_full.json")) as f:
+        golden = json.load(f)[cfg_name]
+    assert golden["seed"] == cfg["seed"] and golden["n"] == cfg["n"]
+    out_host = d_out.cpu().numpy().view(np.uint64).reshape(n, LIMBS)
+    checked, sha_ok, err = verify_against_golden(out_host, golden, first, n)
+    if err:
+        sys.stderr.write("bench.py: rank %d: %s\n" % (rank, err))
+    # every rank learns whether any rank failed, and all leave together (no line is printed)
+    if max_over_ranks(1.0 if err else 0.0, dist, dev if backend == "nccl" else None) != 0.0:
+        if dist is not None:
+            dist.destroy_process_group()
+        raise SystemExit(3)
 
     if rank == 0:
-        # HBM traffic and VALU utilisation come from the committed rocprofv3 --pmc passes of this same
-        # command (profiles/rNN/pmc_k_jive.json): counters cannot be read from inside the process.
-        traffic, valu_busy, mad_frac, prof_src = None, None, None, None
+        # HBM traffic comes from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/rNN/pmc_k_jive.json): counters cannot be read from inside the process.  It is reported
+        # only if that profile was taken from the kernel sources being run.
+        csrc = buildinfo.csrc_sha256()
+        traffic, prof_src, prof_clock, stale = None, None, None, None
         try:
-            prof_dirs = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r"))
+            prof_dirs = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles"))
+                               if d.startswith("r") and os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_k_jive.json")))
             prof_src = os.path.join("profiles", prof_dirs[-1], "pmc_k_jive.json")
-            pmc = json.load(open(os.path.join(ROOT, prof_src)))["derived"]
-            if args.batch_log2 == BATCH_LOG2:
-                traffic = pmc["hbm_traffic_bytes_per_launch"]
-            valu_busy = pmc["valu_issue_model_fraction"]
-            mad_frac = pmc["mad_cycle_fraction"]
+            pmc = json.load(open(os.path.join(ROOT, prof_src)))
+            stale = pmc.get("csrc_sha256") != csrc
+            if not stale:
+                prof_clock = pmc["derived"]["clock_GHz"]
+                if lg == 20:
+                    traffic = pmc["derived"]["hbm_traffic_bytes_per_launch"]
         except Exception:
-            prof_src = None
+            prof_src, stale = None, None
         total_items = n * world * args.steps
         value = total_items / elapsed
         achieved = BYTES_PER_ITEM * n / (kernel_ms * 1e-3) / 1e9
+        mad_per_item = buildinfo.bls12_381_mad_per_compression()
+        lane_mad_per_s = mad_per_item * n / (kernel_ms * 1e-3)
+        clock = prof_clock or NOMINAL_GHZ
         out = {
             "metric": "Jive 2-to-1 compressions/sec (Anemoi-2-1, BLS12-381)",
             "value": value, "unit": "compressions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "Anemoi-2-1 over BLS12-381 basefield, 2^%d batched Jive compressions per GPU, "
-                                   "inputs resident in HBM" % args.batch_log2,
-                       "field": FIELD, "state_width": WIDTH, "batch_per_gpu": n, "parallelism": "shard%d" % world},
+            "config": {"workload": ("BASELINE config 2: Anemoi-2-1 over BLS12-381 basefield, 2^%d batched Jive compressions "
+                                    "on one GPU, inputs resident in HBM" % lg) if world == 1 else
+                                   ("BASELINE config 4: Anemoi-2-1 over BLS12-381, 2^24-state batch in 8 contiguous shards, "
+                                    "rank r runs shard r (2^%d items per GPU, %d of 8 shards), no collective on the data path"
+                                    % (lg, world)),
+                       "field": FIELD, "state_width": WIDTH, "batch_per_gpu": n, "parallelism": "shard%d" % world,
+                       "seed": cfg["seed"], "control_plane": (backend if world > 1 else "none")},
+            "verified": {"against": "tests/golden/cfg_full.json:%s (CPU oracle)" % cfg_name, "items_compared": checked,
+                         "sha256_of_all_outputs": sha_ok, "ranks": world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": stale,
                          "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
-                         "traffic_source": prof_src,
+                         "traffic_source": prof_src, "csrc_sha256": csrc,
                          "kernel": "k_jive<bls12_381,2,2>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_ITEM * n},
             "alu": {"bound": "valu", "modmul_per_s": MODMUL_PER_ITEM * n / (kernel_ms * 1e-3),
-                    "valu_issue_frac_profiled": valu_busy,
-                    "mad_cycle_frac_profiled": mad_frac,
-                    "note": "384-bit Montgomery mul/sqr per second (reference chain count 9576 per compression). "
-                            "The path is VALU-issue bound: in the profiled kernel (SQ_INSTS_VALU, profiles/) "
-                            "v_mad_u64_u32 at 16 lanes per clock alone fills mad_cycle_frac_profiled of all SIMD "
-                            "cycles, and all VALU instructions priced at their measured issue cost fill "
-                            "valu_issue_frac_profiled; see DESIGN.md"},
+                    "mad_per_item": mad_per_item, "lane_mad_per_s": lane_mad_per_s,
+                    "peak_lane_mad_per_s": SIMDS * LANES_PER_CLK * clock * 1e9, "clock_GHz": clock,
+                    "clock_source": "GRBM_GUI_ACTIVE of the committed profile" if prof_clock else "nominal",
+                    "frac": lane_mad_per_s / (SIMDS * LANES_PER_CLK * clock * 1e9),
+                    "note": "v_mad_u64_u32 lane-operations per second (count per compression from the generated assembly: "
+                            "21 rounds x (381 squarings x 260 + 101 multiplications x 338) + 5 x 338) against 1024 SIMDs x "
+                            "16 lanes per clock; the path is VALU-issue bound, see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(synth)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -16,14 +16,34 @@ _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 
+_CLANG = "/opt/rocm/lib/llvm/bin/clang"
+
+
+def _compiler():
+    """The image's clang when present, else gcc without SLP vectorisation (gcc 11 -O3 turns the 6-limb
+    CIOS loops into a 5x slower vector form; see oracle/Makefile)."""
+    if os.path.exists(_CLANG):
+        return [_CLANG, "-O3"]
+    return ["gcc", "-O3", "-fno-tree-slp-vectorize"]
+
+
+def compiler_description():
+    cc = _compiler()
+    try:
+        ver = subprocess.run([cc[0], "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:
+        ver = "?"
+    return "%s (%s)" % (" ".join(os.path.basename(c) if i == 0 else c for i, c in enumerate(cc)), ver)
+
+
 def build(native=False, out=None):
     """Compile the oracle. native=True -> -march=native into `out` (for the CPU baseline on the GPU box)."""
     if not native:
         subprocess.check_call(["make", "-s", "-C", _HERE])
         return os.path.join(_HERE, "liboracle.so")
     out = out or os.path.join(_HERE, "liboracle_native.so")
-    subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=gnu11", "-shared", "-o", out,
-                           os.path.join(_HERE, "anemoi_oracle.c"), "-lpthread"])
+    subprocess.check_call(_compiler() + ["-march=native", "-fPIC", "-std=gnu11", "-shared", "-o", out,
+                                         os.path.join(_HERE, "anemoi_oracle.c"), "-lpthread"])
     return out
 
 

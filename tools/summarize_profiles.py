@@ -15,6 +15,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "anemoi-rust_amd", "anemoi_amd"))
+import buildinfo  # noqa: E402  (plain module import: the package itself needs the HIP library)
+
 KERNEL = "k_jive"
 CUS, SIMDS = 256, 4
 XCDS = 8                 # GRBM_GUI_ACTIVE is reported once per XCD; the sum is divided by this
@@ -50,19 +53,7 @@ def counters(d):
 
 def mad_counts():
     """v_mad_u64_u32 per squaring / multiplication of the shipped BLS12-381 layout, from the generated header"""
-    hdr = open(os.path.join(ROOT, "anemoi-rust_amd", "csrc", "mont29_asm_gen.h")).read()
-    best = None
-    for m in re.finditer(r"// bls12_381, (\d+)-bit limbs: (\d+) limbs; squaring (\d+) instructions \((\d+) v_mad_u64_u32, "
-                         r"\d+ split columns\), multiplication (\d+) \((\d+),", hdr):
-        best = {"limb_bits": int(m.group(1)), "limbs": int(m.group(2)), "sqr_instr": int(m.group(3)),
-                "sqr_mad": int(m.group(4)), "mul_instr": int(m.group(5)), "mul_mad": int(m.group(6))}
-    # the last entry = the widest limbs = the default `Lane` layout; count its 64-bit / multiply VOP3 helpers
-    body = hdr[hdr.index("template <> struct AsmMont<0, %d>" % best["limb_bits"]):]
-    body = body[:body.index("};")]
-    sq, mu = body.split("static __forceinline__ void mul(")
-    wide = lambda s: sum(s.count(op) for op in ("v_lshrrev_b64", "v_lshl_add_u64", "v_mul_lo_u32"))
-    best["sqr_wide"], best["mul_wide"] = wide(sq), wide(mu)
-    return best
+    return buildinfo.bls12_381_limb_layout()
 
 
 def main():
@@ -94,9 +85,10 @@ def main():
     fetch = c["FETCH_SIZE"] * 1024 * 2   # KiB; gfx950 reports half of a wide coalesced read
     write = c["WRITE_SIZE"] * 1024
     mc = mad_counts()
-    rounds, sq_per_round, mul_per_round = 21, 381, 101   # 379 + 2 S-box squarings; 99 + 2 settle() products
-    mad_per_comp = rounds * (sq_per_round * mc["sqr_mad"] + mul_per_round * mc["mul_mad"]) + 3 * mc["mul_mad"]
-    wide_per_comp = rounds * (sq_per_round * mc["sqr_wide"] + mul_per_round * mc["mul_wide"]) + 3 * mc["mul_wide"]
+    rounds = 21
+    sq_per_round, mul_per_round = buildinfo.bls12_381_products_per_round()   # S-box chain + its 2 squarings; + 2 settle()
+    mad_per_comp = buildinfo.bls12_381_mad_per_compression()
+    wide_per_comp = rounds * (sq_per_round * mc["sqr_wide"] + mul_per_round * mc["mul_wide"]) + 5 * mc["mul_wide"]
     gui = c["GRBM_GUI_ACTIVE"] / XCDS
     clock = gui / secs / 1e9
     valu_per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
@@ -125,6 +117,8 @@ def main():
     }
     c["kernel_seconds_in_sq_pass"] = secs
     out = {
+        "csrc_sha256": buildinfo.csrc_sha256(),   # bench.py reports `traffic` only for the sources this describes
+        "products_per_round": {"squarings": sq_per_round, "multiplications": mul_per_round},
         "counters_avg_per_launch": c, "derived": derived, "limb_layout": mc,
         "rocprofv3_stats_avg_ms": sum(dur) / len(dur), "rocprofv3_stats_calls": len(dur),
         "note": "rocprofv3 --pmc passes (separate runs for FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set) of `python3 "
@@ -132,8 +126,8 @@ def main():
                 "the k_jive dispatches, summed over a counter's hardware instances. FETCH_SIZE/WRITE_SIZE are in KiB; "
                 "FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read). "
                 "GRBM_GUI_ACTIVE is summed over the 8 XCDs. SQ_WAVE_CYCLES / SQ_ACTIVE_INST_VALU are quad-cycles. mad_* "
-                "figures: v_mad_u64_u32 counts from the generated assembly (limb_layout), 21 x (381 squarings + 101 "
-                "multiplications) + 3 per compression. Issue model: 4.0 cycles per wave-level v_mad_u64_u32 (16 lanes per "
+                "figures: v_mad_u64_u32 counts from the generated assembly (limb_layout), 21 x (products_per_round) + 5 "
+                "per compression (anemoi_amd/buildinfo.py). Issue model: 4.0 cycles per wave-level v_mad_u64_u32 (16 lanes per "
                 "clock), 4.3 for 64-bit shift/add and v_mul_lo_u32, 2.4 for the remaining VALU instructions "
                 "(tools/ubench/wall_rates.hip).",
     }
