@@ -1,6 +1,7 @@
 """Executes the GENERATED gfx950 assembly of the Montgomery squaring / multiplication
 (anemoi-rust_amd/csrc/mont29_asm_gen.h, tools/gen_asm_mul.py) on a small CPU interpreter of the few
-instructions it uses, with overflow detection on every v_mad_u64_u32 / v_lshl_add_u64.
+instructions it uses, with overflow detection on every v_mad_u64_u32 / v_lshl_add_u64 and on the 32-bit
+column-carry path (v_alignbit_b32: the carry must really fit 32 bits).
 
 Why: the GPU parity tests feed random field elements, which never come near the worst-case limb
 patterns the 64-bit column accumulators are dimensioned for (30-bit limbs: a column holds up to 26
@@ -103,6 +104,14 @@ def run(lines, outs, ins, a, b=None):
         elif op == "v_lshrrev_b64":
             d, sh, s = args
             wr(d, rd(s) >> rd(sh))
+        elif op == "v_alignbit_b32":
+            # D = ({S0, S1} >> S2[4:0]) & 0xffffffff; the generator uses it as "column carry fits 32 bits":
+            # a carry that does not fit would be silently truncated, so that is an overflow here
+            d, hi, lo, sh = args
+            val = ((rd(hi) << 32) | rd(lo)) >> (rd(sh) & 31)
+            if val > M32:
+                raise Overflow(ln)
+            wr(d, val)
         elif op == "v_lshlrev_b32":
             d, sh, s = args
             val = rd(s) << rd(sh)

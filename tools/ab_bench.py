@@ -11,9 +11,9 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "anemoi-rust_amd", "anemoi_amd"))
 import torch  # noqa: E402  (first: one HIP runtime for everything)
-import bench  # noqa: E402
+import synth  # noqa: E402  (plain module import; the libraries under test are loaded explicitly below)
 
 
 def main():
@@ -27,11 +27,8 @@ def main():
     n = 1 << args.log2
     limbs = 6 if args.field in (0, 1) else 4
     dev = torch.device("cuda", 0)
-    host = bench.synth_states(n, 1) if (args.field == 0 and args.width == 2) else None
-    if host is None:
-        import numpy as np
-        rng = np.random.default_rng(1)
-        host = rng.integers(0, 1 << 60, size=(n, args.width, limbs), dtype=np.uint64)
+    fields = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
+    host = synth.states(fields[args.field], args.width, 1, 0, n)
     d_in = torch.from_numpy(host.view("int64").reshape(-1)).to(dev)
     d_out = torch.empty(n * limbs * (args.width // 2), dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()

@@ -48,20 +48,34 @@ class Column:
     limbs every column fits.  With 30-bit limbs (13 limbs for 381/377 bits) the five middle columns do
     not: there the accumulator is split once -- its upper word parked in T, the low word kept (the
     reduction digit and the output limb only look at the low W bits) -- and T << (32 - W) is added
-    back after the column's shift."""
+    back after the column's shift.
 
-    def __init__(self, out, W, acc, treg):
-        self.out, self.W, self.acc, self.treg = out, W, acc, treg
+    Column carry.  The carry into the next column is ACC >> W.  A 64-bit shift costs as much as a
+    multiply-add (4.3 cycles per wave-instruction, tools/ubench/wall_rates.hip); where the bound shows the
+    carry fits 32 bits (ACC < 2^(32 + W): the light columns at both ends -- most columns of a 9-limb
+    product) it is taken with ONE 32-bit funnel shift (v_alignbit_b32, 2.4 cycles) into the low half of
+    the register pair [C, Z], Z a register that is zero for the whole statement, and the next column's
+    first multiply-add reads that pair as its addend (v_mad_u64_u32 ACC, a, b, [C:Z]) -- so the
+    accumulator is re-initialised for free.  The first column starts from the inline constant 0."""
+
+    def __init__(self, out, W, acc, treg, cz=None):
+        self.out, self.W, self.acc, self.treg, self.cz = out, W, acc, treg, cz
         self.ACC = "v[%d:%d]" % (acc, acc + 1)
         self.T = "v[%d:%d]" % (treg, treg + 1)
+        self.CZ = "v[%d:%d]" % (cz, cz + 1) if cz is not None else None
         self.bound = 0          # upper bound of ACC
         self.tbound = None      # upper bound of T while a split is pending
         self.splits = 0
+        self.addend = "0"       # what the next column's first multiply-add adds: "0", ACC or the [C, Z] pair
+        self.light = 0          # columns whose carry took the 32-bit path
+        if cz is not None:
+            out.append("v_mov_b32 v%d, 0" % (cz + 1))
 
     def mad(self, a, b, amax, bmax):
         term = amax * bmax
         if self.bound + term >= CAP:
             assert self.tbound is None, "a column needs more than one split"
+            assert self.addend == self.ACC, "a split before the column's first multiply-add"
             # park the accumulator's upper word: column value = (T << 32) + ACC from here on
             if self.splits == 0:
                 self.out.append("v_mov_b32 v%d, 0" % (self.treg + 1))
@@ -70,11 +84,28 @@ class Column:
             self.tbound = self.bound >> 32
             self.bound = (1 << 32) - 1
             self.splits += 1
-        self.out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (self.ACC, a, b, self.ACC))
+        self.out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (self.ACC, a, b, self.addend))
+        self.addend = self.ACC
         self.bound += term
         assert self.bound < CAP
 
-    def shift(self):
+    def low(self):
+        """register holding the low word of the column sum (valid once the column has a multiply-add)"""
+        assert self.addend == self.ACC
+        return "v%d" % self.acc
+
+    def shift(self, final_dst=None):
+        """end of a column: ACC >>= W (or the 32-bit carry path).  final_dst: the last column writes its
+        (< 2^32) carry straight into the top output limb."""
+        assert self.addend == self.ACC
+        if self.tbound is None and self.bound < (1 << (32 + self.W)) and (final_dst or self.CZ):
+            dst = final_dst or ("v%d" % self.cz)
+            self.out.append("v_alignbit_b32 %s, v%d, v%d, %d" % (dst, self.acc + 1, self.acc, self.W))
+            self.bound >>= self.W
+            self.light += 1
+            if not final_dst:
+                self.addend = self.CZ
+            return
         self.out.append("v_lshrrev_b64 %s, %d, %s" % (self.ACC, self.W, self.ACC))
         self.bound >>= self.W
         if self.tbound is not None:
@@ -82,6 +113,8 @@ class Column:
             self.bound += self.tbound << (32 - self.W)
             assert self.bound < CAP
             self.tbound = None
+        if final_dst:
+            self.out.append("v_mov_b32 %s, v%d" % (final_dst, self.acc))
 
 
 def top_limb_bound(p, W, nl, mult):
@@ -107,15 +140,14 @@ def gen_sqr(nl, plimbs, n0inv, W, p=None):
     a2 = TMP_BASE + 2              # nl regs
     m = a2 + nl                    # nl regs
     treg = (m + nl + 1) & ~1      # 2 regs (64-bit aligned), only touched when a column is split
+    cz = treg if W == 29 else None   # [carry, zero] pair of the 32-bit carry path (29-bit limbs never split)
     A = lambda i: "%%%d" % i
     P = lambda i: "%%%d" % (nl + i)
     N0 = "%%%d" % (2 * nl)
     out = []
     for j in range(nl):
         out.append("v_lshlrev_b32 v%d, 1, %s" % (a2 + j, A(j)))
-    out.append("v_mov_b32 v%d, 0" % acc)
-    out.append("v_mov_b32 v%d, 0" % (acc + 1))
-    col = Column(out, W, acc, treg)
+    col = Column(out, W, acc, treg, cz)
     ACC = col.ACC
     for k in range(2 * nl - 1):
         j0 = 0 if k < nl else k - nl + 1
@@ -130,24 +162,23 @@ def gen_sqr(nl, plimbs, n0inv, W, p=None):
                 if plimbs[k - j]:
                     col.mad("v%d" % (m + j), P(k - j), MASK, plimbs[k - j])
             if n0inv == MASK:   # p = 1 mod 2^W: m = -lo mod 2^W
-                out.append("v_sub_u32 v%d, 0, v%d" % (m + k, acc))
+                out.append("v_sub_u32 v%d, 0, %s" % (m + k, col.low()))
             else:
-                out.append("v_mul_lo_u32 v%d, v%d, %s" % (m + k, acc, N0))
+                out.append("v_mul_lo_u32 v%d, %s, %s" % (m + k, col.low(), N0))
             out.append("v_and_b32 v%d, 0x%x, v%d" % (m + k, MASK, m + k))
             col.mad("v%d" % (m + k), P(0), MASK, plimbs[0])
         else:
             for j in range(k - nl + 1, nl):
                 if plimbs[k - j]:
                     col.mad("v%d" % (m + j), P(k - j), MASK, plimbs[k - j])
-            out.append("v_and_b32 %s, 0x%x, v%d" % (A(k - nl), MASK, acc))   # a_{k-nl} is dead from here on
-        col.shift()
-    out.append("v_mov_b32 %s, v%d" % (A(nl - 1), acc))
+            out.append("v_and_b32 %s, 0x%x, %s" % (A(k - nl), MASK, col.low()))   # a_{k-nl} is dead from here on
+        col.shift(A(nl - 1) if k == 2 * nl - 2 else None)
     # 13/14-limb fields always claim the full 30-register window (through v129 at the default base): a kernel that ends
     # up with <= 128 VGPRs is allowed 4 wavefronts per SIMD, LDS then caps the CU at 12, and the
     # resulting 4,4,4,0 placement is ~9 % slower than 3,3,3,3 (measured on BLS12-377, 30-bit limbs).
-    ntmp = max(treg + 2, TMP_BASE + 30) if nl >= 13 else m + nl
+    ntmp = max(treg + 2, TMP_BASE + 30) if nl >= 13 else (treg + 2 if cz is not None else m + nl)
     clob = ["v%d" % r for r in range(TMP_BASE, ntmp)] + ["vcc"]
-    return out, clob, col.splits
+    return out, clob, col.splits, col.light
 
 
 def gen_mul(nl, plimbs, n0inv, W, p=None):
@@ -159,6 +190,7 @@ def gen_mul(nl, plimbs, n0inv, W, p=None):
     acc = TMP_BASE
     m = TMP_BASE + 2
     treg = (m + nl + 1) & ~1
+    cz = treg if W == 29 else None
     A = lambda i: "%%%d" % i
     B = lambda i: "%%%d" % (nl + i)
     SP = lambda i: "s%d" % (SGPR_BASE + i)
@@ -167,9 +199,7 @@ def gen_mul(nl, plimbs, n0inv, W, p=None):
     for i in range(nl):
         out.append("s_mov_b32 %s, 0x%x" % (SP(i), plimbs[i]))
     out.append("s_mov_b32 %s, 0x%x" % (SN0, n0inv))
-    out.append("v_mov_b32 v%d, 0" % acc)
-    out.append("v_mov_b32 v%d, 0" % (acc + 1))
-    col = Column(out, W, acc, treg)
+    col = Column(out, W, acc, treg, cz)
     for k in range(2 * nl - 1):
         j0, j1 = (0, k) if k < nl else (k - nl + 1, nl - 1)
         for j in range(j0, j1 + 1):
@@ -179,21 +209,20 @@ def gen_mul(nl, plimbs, n0inv, W, p=None):
                 if plimbs[k - j]:
                     col.mad("v%d" % (m + j), SP(k - j), MASK, plimbs[k - j])
             if n0inv == MASK:
-                out.append("v_sub_u32 v%d, 0, v%d" % (m + k, acc))
+                out.append("v_sub_u32 v%d, 0, %s" % (m + k, col.low()))
             else:
-                out.append("v_mul_lo_u32 v%d, v%d, %s" % (m + k, acc, SN0))
+                out.append("v_mul_lo_u32 v%d, %s, %s" % (m + k, col.low(), SN0))
             out.append("v_and_b32 v%d, 0x%x, v%d" % (m + k, MASK, m + k))
             col.mad("v%d" % (m + k), SP(0), MASK, plimbs[0])
         else:
             for j in range(k - nl + 1, nl):
                 if plimbs[k - j]:
                     col.mad("v%d" % (m + j), SP(k - j), MASK, plimbs[k - j])
-            out.append("v_and_b32 %s, 0x%x, v%d" % (A(k - nl), MASK, acc))
-        col.shift()
-    out.append("v_mov_b32 %s, v%d" % (A(nl - 1), acc))
-    ntmp = treg + 2 if col.splits else m + nl
+            out.append("v_and_b32 %s, 0x%x, %s" % (A(k - nl), MASK, col.low()))
+        col.shift(A(nl - 1) if k == 2 * nl - 2 else None)
+    ntmp = treg + 2 if (col.splits or cz is not None) else m + nl
     clob = (["v%d" % r for r in range(TMP_BASE, ntmp)] + ["s%d" % (SGPR_BASE + i) for i in range(nl + 1)] + ["vcc"])
-    return out, clob, col.splits
+    return out, clob, col.splits, col.light
 
 
 COOP_VBASE, COOP_SBASE = 60, 60   # fixed (clobbered) registers of the cooperative product
@@ -261,12 +290,14 @@ def main():
         p = int(params[name]["modulus"])
         for W in ((29, 30) if p.bit_length() > 300 else (29,)):
             nl, pl, n0 = field_consts(p, W)
-            sq, sq_clob, sq_splits = gen_sqr(nl, pl, n0, W, p)
-            mu, mu_clob, mu_splits = gen_mul(nl, pl, n0, W, p)
+            sq, sq_clob, sq_splits, sq_light = gen_sqr(nl, pl, n0, W, p)
+            mu, mu_clob, mu_splits, mu_light = gen_mul(nl, pl, n0, W, p)
             nmad = sum(1 for l in sq if l.startswith("v_mad"))
             h.append("// %s, %d-bit limbs: %d limbs; squaring %d instructions (%d v_mad_u64_u32, %d split columns), "
                      "multiplication %d (%d, %d)" % (name, W, nl, len(sq), nmad, sq_splits, len(mu),
                                                      sum(1 for l in mu if l.startswith("v_mad")), mu_splits))
+            h.append("//   32-bit column carries (v_alignbit_b32 instead of v_lshrrev_b64): %d of %d columns (squaring), "
+                     "%d (multiplication)" % (sq_light, 2 * nl - 1, mu_light))
             h.append("template <> struct AsmMont<%d, %d> {" % (fid, W))
             h.append("  static constexpr int NL = %d;" % nl)
             h.append("  __device__ static __forceinline__ void sqr(uint32_t (&a)[NL]) {")
