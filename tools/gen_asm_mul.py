@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELD_IDS = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
 TMP_BASE = int(os.environ.get("ANEMOI_ASM_TMP_BASE", "100"))  # clobbered VGPRs start here (even: the 64-bit accumulator is 2-aligned)
 SGPR_BASE = 60      # clobbered SGPRs of the multiplication
+CHAINS = int(os.environ.get("ANEMOI_ASM_CHAINS", "1"))   # independent multiply-add chains per column (see Column.mads)
 CAP = 1 << 64
 
 
@@ -58,8 +59,10 @@ class Column:
     first multiply-add reads that pair as its addend (v_mad_u64_u32 ACC, a, b, [C:Z]) -- so the
     accumulator is re-initialised for free.  The first column starts from the inline constant 0."""
 
-    def __init__(self, out, W, acc, treg, cz=None):
+    def __init__(self, out, W, acc, treg, cz=None, xacc=()):
         self.out, self.W, self.acc, self.treg, self.cz = out, W, acc, treg, cz
+        self.xacc = list(xacc)  # extra accumulator pairs: independent multiply-add chains inside a column
+        self.multi = 0          # columns that used them
         self.ACC = "v[%d:%d]" % (acc, acc + 1)
         self.T = "v[%d:%d]" % (treg, treg + 1)
         self.CZ = "v[%d:%d]" % (cz, cz + 1) if cz is not None else None
@@ -88,6 +91,36 @@ class Column:
         self.addend = self.ACC
         self.bound += term
         assert self.bound < CAP
+
+    def mads(self, terms, reserve=0):
+        """The multiply-adds of a column, terms = [(a, b, amax, bmax)].  With extra accumulators the terms go
+        round-robin onto 1 + len(xacc) independent chains (a lone wavefront issues dependent and independent
+        v_mad_u64_u32 alike, but at 3 waves per SIMD independent chains issue ~2-7 % faster:
+        tools/ubench/wall_chains.hip) and are summed with v_lshl_add_u64 at the end -- only in columns whose
+        total (plus `reserve`, the m_k p_0 term still to come) provably fits 64 bits, so that no chain and no
+        partial sum can overflow; the heavy middle columns of the 30-bit layout keep the single chain and
+        its split."""
+        total = self.bound + sum(x * y for _, _, x, y in terms)
+        n = min(1 + len(self.xacc), len(terms))
+        if n < 2 or total + reserve >= CAP or self.tbound is not None:
+            for t in terms:
+                self.mad(*t)
+            return
+        started = set()
+        for i, (a, b, _, _) in enumerate(terms):
+            c = i % n
+            if c == 0:
+                self.out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (self.ACC, a, b, self.addend))
+                self.addend = self.ACC
+            else:
+                X = "v[%d:%d]" % (self.xacc[c - 1], self.xacc[c - 1] + 1)
+                self.out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (X, a, b, X if c in started else "0"))
+                started.add(c)
+        for c in sorted(started):
+            X = "v[%d:%d]" % (self.xacc[c - 1], self.xacc[c - 1] + 1)
+            self.out.append("v_lshl_add_u64 %s, %s, 0, %s" % (self.ACC, X, self.ACC))
+        self.bound = total
+        self.multi += 1
 
     def low(self):
         """register holding the low word of the column sum (valid once the column has a multiply-add)"""
@@ -147,20 +180,23 @@ def gen_sqr(nl, plimbs, n0inv, W, p=None):
     out = []
     for j in range(nl):
         out.append("v_lshlrev_b32 v%d, 1, %s" % (a2 + j, A(j)))
-    col = Column(out, W, acc, treg, cz)
+    xacc = [((treg + 2 + 1) & ~1) + 2 * i for i in range(CHAINS - 1)]
+    col = Column(out, W, acc, treg, cz, xacc)
     ACC = col.ACC
     for k in range(2 * nl - 1):
         j0 = 0 if k < nl else k - nl + 1
         j = j0
+        terms = []
         while j < k - j:
-            col.mad("v%d" % (a2 + j), A(k - j), 2 * amax[j], amax[k - j])
+            terms.append(("v%d" % (a2 + j), A(k - j), 2 * amax[j], amax[k - j]))
             j += 1
         if k % 2 == 0:
-            col.mad(A(k // 2), A(k // 2), amax[k // 2], amax[k // 2])
+            terms.append((A(k // 2), A(k // 2), amax[k // 2], amax[k // 2]))
         if k < nl:
             for j in range(k):
                 if plimbs[k - j]:
-                    col.mad("v%d" % (m + j), P(k - j), MASK, plimbs[k - j])
+                    terms.append(("v%d" % (m + j), P(k - j), MASK, plimbs[k - j]))
+            col.mads(terms, MASK * plimbs[0])
             if n0inv == MASK:   # p = 1 mod 2^W: m = -lo mod 2^W
                 out.append("v_sub_u32 v%d, 0, %s" % (m + k, col.low()))
             else:
@@ -170,13 +206,16 @@ def gen_sqr(nl, plimbs, n0inv, W, p=None):
         else:
             for j in range(k - nl + 1, nl):
                 if plimbs[k - j]:
-                    col.mad("v%d" % (m + j), P(k - j), MASK, plimbs[k - j])
+                    terms.append(("v%d" % (m + j), P(k - j), MASK, plimbs[k - j]))
+            col.mads(terms)
             out.append("v_and_b32 %s, 0x%x, %s" % (A(k - nl), MASK, col.low()))   # a_{k-nl} is dead from here on
         col.shift(A(nl - 1) if k == 2 * nl - 2 else None)
     # 13/14-limb fields always claim the full 30-register window (through v129 at the default base): a kernel that ends
     # up with <= 128 VGPRs is allowed 4 wavefronts per SIMD, LDS then caps the CU at 12, and the
     # resulting 4,4,4,0 placement is ~9 % slower than 3,3,3,3 (measured on BLS12-377, 30-bit limbs).
     ntmp = max(treg + 2, TMP_BASE + 30) if nl >= 13 else (treg + 2 if cz is not None else m + nl)
+    if xacc:
+        ntmp = max(ntmp, xacc[-1] + 2)
     clob = ["v%d" % r for r in range(TMP_BASE, ntmp)] + ["vcc"]
     return out, clob, col.splits, col.light
 
@@ -199,15 +238,16 @@ def gen_mul(nl, plimbs, n0inv, W, p=None):
     for i in range(nl):
         out.append("s_mov_b32 %s, 0x%x" % (SP(i), plimbs[i]))
     out.append("s_mov_b32 %s, 0x%x" % (SN0, n0inv))
-    col = Column(out, W, acc, treg, cz)
+    xacc = [((treg + 2 + 1) & ~1) + 2 * i for i in range(CHAINS - 1)]
+    col = Column(out, W, acc, treg, cz, xacc)
     for k in range(2 * nl - 1):
         j0, j1 = (0, k) if k < nl else (k - nl + 1, nl - 1)
-        for j in range(j0, j1 + 1):
-            col.mad(A(j), B(k - j), MASK, bmax[k - j])
+        terms = [(A(j), B(k - j), MASK, bmax[k - j]) for j in range(j0, j1 + 1)]
         if k < nl:
             for j in range(k):
                 if plimbs[k - j]:
-                    col.mad("v%d" % (m + j), SP(k - j), MASK, plimbs[k - j])
+                    terms.append(("v%d" % (m + j), SP(k - j), MASK, plimbs[k - j]))
+            col.mads(terms, MASK * plimbs[0])
             if n0inv == MASK:
                 out.append("v_sub_u32 v%d, 0, %s" % (m + k, col.low()))
             else:
@@ -217,10 +257,13 @@ def gen_mul(nl, plimbs, n0inv, W, p=None):
         else:
             for j in range(k - nl + 1, nl):
                 if plimbs[k - j]:
-                    col.mad("v%d" % (m + j), SP(k - j), MASK, plimbs[k - j])
+                    terms.append(("v%d" % (m + j), SP(k - j), MASK, plimbs[k - j]))
+            col.mads(terms)
             out.append("v_and_b32 %s, 0x%x, %s" % (A(k - nl), MASK, col.low()))
         col.shift(A(nl - 1) if k == 2 * nl - 2 else None)
     ntmp = treg + 2 if (col.splits or cz is not None) else m + nl
+    if xacc:
+        ntmp = max(ntmp, xacc[-1] + 2)
     clob = (["v%d" % r for r in range(TMP_BASE, ntmp)] + ["s%d" % (SGPR_BASE + i) for i in range(nl + 1)] + ["vcc"])
     return out, clob, col.splits, col.light
 
