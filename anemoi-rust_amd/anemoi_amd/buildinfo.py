@@ -10,10 +10,14 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_ROOT, "csrc")
 
 
+HOST_ONLY = ("capi.hip", "runtime.h", "host_logic.h")   # no device code: they cannot change a kernel
+
+
 def csrc_sha256():
-    """SHA-256 over the kernel / runtime sources and the Makefile (file names and contents, sorted)."""
+    """SHA-256 over the KERNEL sources and the Makefile (file names and contents, sorted): every csrc file
+    except the host-only ones."""
     h = hashlib.sha256()
-    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")) and f not in HOST_ONLY)
     for path in [os.path.join(CSRC, f) for f in files] + [os.path.join(_ROOT, "Makefile")]:
         h.update(os.path.basename(path).encode() + b"\0")
         h.update(open(path, "rb").read())

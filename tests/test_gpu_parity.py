@@ -283,7 +283,7 @@ def test_cfg1_vesta_1024(A, oracle, params):
 
 
 def test_cfg2_bls12_381_2pow20(A, oracle, params):
-    """BASELINE config 2: 2^20 BLS12-381 Anemoi-2-1 compressions.  Oracle on a 512-item sample +
+    """BASELINE config 2: 2^20 BLS12-381 Anemoi-2-1 compressions drawn from 4 096 distinct states, every one checked against the oracle, +
     size-independent properties: batch == items run alone, shuffle-equivariance, ALL_DEVICES == 1 GPU."""
     fid, p, n = 0, int(params["bls12_381"]["modulus"]), 1 << 20
     rng = np.random.default_rng(0xA9E30102)
@@ -294,7 +294,7 @@ def test_cfg2_bls12_381_2pow20(A, oracle, params):
     out = inst.compress_batch(st)
     assert out.shape == (n, 1, 6)
     ref = inst.compress_batch(base)
-    assert (ref[:512] == oracle.compress_batch(fid, 2, base[:512], threads=8)).all()
+    assert (ref == oracle.compress_batch(fid, 2, base, threads=8)).all()      # all 4 096 distinct states
     # equal inputs -> equal outputs, everywhere in the batch (catches any index-dependent corruption)
     assert (out == ref[idx]).all()
     # sharding over all visible GPUs gives the same bytes
