@@ -204,7 +204,7 @@ ANEMOI_KERNEL void k_sponge_cols(const void* __restrict__ src, size_t per_msg, s
 #pragma nounroll
   for (size_t e = 0; e < total; e++) {
     typename A::Fe el, t;
-    sponge_element<F, A, BYTES>(el, msg, e, num, per_msg);
+    sponge_element<F, A, BYTES>(el, msg, e, 0, num, per_msg);
     A::add(t, x, el);
     fe_select<A>(x, pos < c && geo.col == pos, t, x);
     A::add(t, y, el);

@@ -222,18 +222,29 @@ __device__ __forceinline__ void chunk_to_fe(typename A::Fe& e, const uint8_t* __
   A::from_int(e, w);
 }
 
+// One launch of a sponge kernel absorbs one SEGMENT of every message: elements [e0, e0 + seg_elems) (to the
+// end, padding included, when `last`).  The whole-message launch is the segment with first = last = 1.
+// Long messages from host memory are fed segment by segment (capi.hip: the copy of segment c + 1 runs under
+// the kernel of segment c), the sponge state carried between launches in `state` as ABI elements.
+struct SpongeSeg {
+  uint32_t* state;   // [n][W] ABI elements, read unless `first`, written unless `last`; may be null if first && last
+  size_t e0;         // index (within the message) of the segment's first element: a multiple of RATE
+  size_t total_len;  // length of the WHOLE message: bytes (BYTES) or elements
+  int first, last;
+};
+
 // Element e of a message as the sponge absorbs it: chunk e of a byte message (BYTES) or ABI element e,
 // and the padding element 1 once the message is exhausted (e == num, only when num % RATE != 0).
+// `seg` points at the segment's first element; total_len is the whole message's length.
 template <class F, class A, bool BYTES>
-__device__ __forceinline__ void sponge_element(typename A::Fe& el, const uint8_t* __restrict__ msg, size_t e, size_t num,
-                                               size_t per_msg) {
+__device__ __forceinline__ void sponge_element(typename A::Fe& el, const uint8_t* __restrict__ seg, size_t e, size_t e0,
+                                               size_t num, size_t total_len) {
   if (e < num) {
     if (BYTES) {
-      const size_t off = e * F::kChunk;
-      const size_t left = per_msg - off;
-      chunk_to_fe<F, A>(el, msg + off, left < size_t(F::kChunk) ? int(left) : F::kChunk);
+      const size_t left = total_len - e * F::kChunk;
+      chunk_to_fe<F, A>(el, seg + (e - e0) * F::kChunk, left < size_t(F::kChunk) ? int(left) : F::kChunk);
     } else {
-      const uint32_t* src32 = (const uint32_t*)msg + e * A::NABI;
+      const uint32_t* src32 = (const uint32_t*)seg + (e - e0) * A::NABI;
       uint32_t w[A::NABI];
 #pragma unroll
       for (int l = 0; l < A::NABI; l++) w[l] = src32[l];
@@ -244,12 +255,28 @@ __device__ __forceinline__ void sponge_element(typename A::Fe& el, const uint8_t
   }
 }
 
+// sponge state element <-> the carry buffer (ABI words, canonical)
+template <class A>
+__device__ __forceinline__ void state_load(typename A::Fe& v, const uint32_t* __restrict__ p) {
+  uint32_t w[A::NABI];
+#pragma unroll
+  for (int l = 0; l < A::NABI; l++) w[l] = p[l];
+  A::from_abi(v, w);
+}
+template <class A>
+__device__ __forceinline__ void state_store(uint32_t* __restrict__ p, const typename A::Fe& v) {
+  uint32_t w[A::NABI];
+  A::to_abi(w, v);
+#pragma unroll
+  for (int l = 0; l < A::NABI; l++) p[l] = w[l];
+}
+
 // Sponge over `num` elements per message (BYTES: taken from msg_len-byte messages; else ABI
 // elements).  Unified rule (== both hasher.rs variants): absorb into state[i]; permute when
 // i == RATE; if num % RATE != 0 absorb a final 1 and permute; digest = state[0].
 template <int FIELD, int W, bool BYTES>
 ANEMOI_KERNEL void k_sponge(const void* __restrict__ src, size_t per_msg, size_t n,
-                                                   uint4* __restrict__ out, PermConsts pc) {
+                                                   uint4* __restrict__ out, PermConsts pc, SpongeSeg seg) {
   using F = FieldC<FIELD>;
   using A = ArithFor<FIELD>;
   constexpr int WIN = KernelCfg<F::N>::WIN, RATE = W - 1;
@@ -257,17 +284,20 @@ ANEMOI_KERNEL void k_sponge(const void* __restrict__ src, size_t per_msg, size_t
   const size_t blk0 = size_t(blockIdx.x) * kBlock;
   const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
   const size_t item = blk0 + (threadIdx.x < cnt ? threadIdx.x : 0);  // idle lanes redo item blk0
-  const size_t num = BYTES ? (per_msg + F::kChunk - 1) / F::kChunk : per_msg;
+  // per_msg = this launch's bytes / elements per message (the stride of `src`); seg.total_len = the whole message
+  const size_t num = BYTES ? (seg.total_len + F::kChunk - 1) / F::kChunk : seg.total_len;
   const size_t total = num + (num % RATE == 0 ? 0 : 1);
+  const size_t e_end = seg.last ? total : seg.e0 + (BYTES ? per_msg / F::kChunk : per_msg);
   const uint8_t* msg = (const uint8_t*)src + (BYTES ? item * per_msg : item * per_msg * A::NABI * 4);
   typename A::Fe st[W];
-  static_for<0, W>([&](auto i) { A::set_zero(st[i]); });
+  if (seg.first) static_for<0, W>([&](auto i) { A::set_zero(st[i]); });
+  else static_for<0, W>([&](auto i) { state_load<A>(st[i], seg.state + (item * W + i) * A::NABI); });
   int pos = 0;
   const LdsTable<A> tab = make_table<A>(lds);
 #pragma nounroll
-  for (size_t e = 0; e < total; e++) {
+  for (size_t e = seg.e0; e < e_end; e++) {
     typename A::Fe el;
-    sponge_element<F, A, BYTES>(el, msg, e, num, per_msg);
+    sponge_element<F, A, BYTES>(el, msg, e, seg.e0, num, seg.total_len);
     // pos is wave-uniform (every message has the same length)
     if (RATE == 1 || pos == 0) A::add(st[0], st[0], el);
     else if (pos == 1) A::add(st[1], st[1], el);
@@ -277,6 +307,10 @@ ANEMOI_KERNEL void k_sponge(const void* __restrict__ src, size_t per_msg, size_t
       permutation<F, A, W, WIN>(st, pc, tab);
       pos = 0;
     }
+  }
+  if (!seg.last) {  // carry the state to the next segment's launch
+    if (threadIdx.x < cnt) static_for<0, W>([&](auto i) { state_store<A>(seg.state + (item * W + i) * A::NABI, st[i]); });
+    return;
   }
   __syncthreads();
   lds_put<A>(lds, threadIdx.x, st[0]);
@@ -352,7 +386,7 @@ ANEMOI_KERNEL void k_jive_pair(const uint4* __restrict__ in, uint4* __restrict__
 // lane, state[2] = y of the even lane).
 template <int FIELD, bool BYTES>
 ANEMOI_KERNEL void k_sponge_pair(const void* __restrict__ src, size_t per_msg, size_t n, uint4* __restrict__ out,
-                                 PermConsts pc) {
+                                 PermConsts pc, SpongeSeg seg) {
   using F = FieldC<FIELD>;
   using A = ArithFor<FIELD>;
   constexpr int WIN = KernelCfg<F::N>::WIN, RATE = 3;
@@ -362,18 +396,24 @@ ANEMOI_KERNEL void k_sponge_pair(const void* __restrict__ src, size_t per_msg, s
   const bool odd = threadIdx.x & 1;
   const int s = threadIdx.x >> 1;
   const size_t item = st0 + (s < cnt ? s : 0);  // idle lane pairs redo item st0
-  const size_t num = BYTES ? (per_msg + F::kChunk - 1) / F::kChunk : per_msg;
+  const size_t num = BYTES ? (seg.total_len + F::kChunk - 1) / F::kChunk : seg.total_len;
   const size_t total = num + (num % RATE == 0 ? 0 : 1);
+  const size_t e_end = seg.last ? total : seg.e0 + (BYTES ? per_msg / F::kChunk : per_msg);
   const uint8_t* msg = (const uint8_t*)src + (BYTES ? item * per_msg : item * per_msg * A::NABI * 4);
   typename A::Fe x, y;
-  A::set_zero(x);
-  A::set_zero(y);
+  if (seg.first) {
+    A::set_zero(x);
+    A::set_zero(y);
+  } else {  // state[0], state[1] = x of the even / odd lane; state[2], state[3] = y of the even / odd lane
+    state_load<A>(x, seg.state + (item * 4 + (odd ? 1 : 0)) * A::NABI);
+    state_load<A>(y, seg.state + (item * 4 + 2 + (odd ? 1 : 0)) * A::NABI);
+  }
   int pos = 0;
   const LdsTable<A> tab = make_table<A>(lds);
 #pragma nounroll
-  for (size_t e = 0; e < total; e++) {
+  for (size_t e = seg.e0; e < e_end; e++) {
     typename A::Fe el, t;
-    sponge_element<F, A, BYTES>(el, msg, e, num, per_msg);
+    sponge_element<F, A, BYTES>(el, msg, e, seg.e0, num, seg.total_len);
     // pos is wave-uniform: state[0] -> even.x, state[1] -> odd.x, state[2] -> even.y
     if (pos < 2) {
       A::add(t, x, el);
@@ -387,6 +427,13 @@ ANEMOI_KERNEL void k_sponge_pair(const void* __restrict__ src, size_t per_msg, s
       permutation_pair<F, A, WIN>(x, y, odd, pc, tab);
       pos = 0;
     }
+  }
+  if (!seg.last) {
+    if (s < cnt) {
+      state_store<A>(seg.state + (item * 4 + (odd ? 1 : 0)) * A::NABI, x);
+      state_store<A>(seg.state + (item * 4 + 2 + (odd ? 1 : 0)) * A::NABI, y);
+    }
+    return;
   }
   __syncthreads();
   // digest = state[0] = the even lane's x; odd lanes write to scratch slots beyond the outputs
@@ -571,6 +618,9 @@ struct FieldOps {
   hipError_t (*jive)(int width, int k, const void* d_in, void* d_out, size_t n, PermConsts pc, hipStream_t s);
   hipError_t (*sponge)(int width, int bytes, const void* d_src, size_t per_msg, size_t n, void* d_out, PermConsts pc,
                        hipStream_t s);
+  // one segment of every message (SpongeSeg): per_msg = this launch's bytes / elements per message
+  hipError_t (*sponge_seg)(int width, int bytes, const void* d_src, size_t per_msg, size_t n, void* d_out, PermConsts pc,
+                           SpongeSeg seg, hipStream_t s);
   hipError_t (*mont_convert)(int to, const void* d_in, void* d_out, size_t count, hipStream_t s);
   hipError_t (*merkle_climb)(const void* d_leaves, const void* d_index, const void* d_paths, unsigned depth, size_t n,
                              void* d_out, PermConsts pc, hipStream_t s);
@@ -667,19 +717,24 @@ struct Launch {
     return hipGetLastError();
   }
 
-  static hipError_t sponge(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
-                           hipStream_t s) {
+  static hipError_t sponge_seg(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
+                               SpongeSeg seg, hipStream_t s) {
     if (!n) return hipSuccess;
     const size_t l = lds_bytes<A, WIN, 1>();
     if (width == 2 && bytes)
-      k_sponge<FIELD, 2, true><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc);
+      k_sponge<FIELD, 2, true><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc, seg);
     else if (width == 2)
-      k_sponge<FIELD, 2, false><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc);
+      k_sponge<FIELD, 2, false><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc, seg);
     else if (bytes)
-      k_sponge_pair<FIELD, true><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(src, per_msg, n, (uint4*)out, pc);
+      k_sponge_pair<FIELD, true><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(src, per_msg, n, (uint4*)out, pc, seg);
     else
-      k_sponge_pair<FIELD, false><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(src, per_msg, n, (uint4*)out, pc);
+      k_sponge_pair<FIELD, false><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(src, per_msg, n, (uint4*)out, pc, seg);
     return hipGetLastError();
+  }
+
+  static hipError_t sponge(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
+                           hipStream_t s) {
+    return sponge_seg(width, bytes, src, per_msg, n, out, pc, SpongeSeg{nullptr, 0, per_msg, 1, 1}, s);
   }
 
   static hipError_t mont_convert(int to, const void* in, void* out, size_t count, hipStream_t s) {
@@ -756,7 +811,7 @@ struct Launch {
 
   static const FieldOps* ops() {
     static const FieldOps o{F::L64,       F::kChunk,    F::kRounds21,        F::kRounds43, F::kG, F::kAlpha, F::kName,
-                            host_consts,  permutation,  jive,                sponge,       mont_convert,
+                            host_consts,  permutation,  jive,                sponge,       sponge_seg,   mont_convert,
                             merkle_climb, generic_permutation, generic_jive, generic_sponge, exp_alpha, wave_items};
     return &o;
   }

@@ -253,6 +253,96 @@ int subtree_host(Lane& ln, TreeShape ts, const char* leaves, unsigned depth, cha
   return ANEMOI_OK;
 }
 
+// ---- sponge over long messages from host memory -------------------------------------------------------
+// A batch too small to be cut into message chunks (fewer than two full waves of workgroups: config 3's
+// 2^16 messages are 2/3 of one) but with a lot of bytes per message (config 3: 640 MiB) would pay the whole
+// copy-in before its single launch.  It is cut ALONG the messages instead: segment c = bytes / elements
+// [c S, (c+1) S) of every message, S a multiple of RATE elements so a segment starts on a permutation
+// boundary; the kernel of segment c runs while segment c + 1 is gathered (one strided copy per message) and
+// copied in; the sponge state travels from launch to launch in a device buffer (SpongeSeg).
+constexpr size_t kSegmentMinBytes = size_t(64) << 20;   // below this the single launch is kept
+
+size_t segment_target_bytes() {
+  const char* e = getenv("ANEMOI_SPONGE_SEGMENT_BYTES");   // test knob: force (small) segments
+  if (e && *e) return size_t(strtoull(e, nullptr, 10));
+  return rt::kChunkTargetBytes;
+}
+
+// unit = bytes of RATE elements of input (BYTES: RATE x chunk bytes; else RATE x element bytes)
+bool want_segments(size_t n, size_t per_msg_bytes, size_t unit) {
+  const bool forced = getenv("ANEMOI_SPONGE_SEGMENT_BYTES") != nullptr;
+  if (!forced && n * per_msg_bytes < kSegmentMinBytes) return false;
+  size_t seg = segment_target_bytes() / (n ? n : 1) / unit * unit;
+  if (seg < unit) seg = unit;
+  return per_msg_bytes > 2 * seg;   // at least three segments, else nothing overlaps
+}
+
+int sponge_segments(Lane& ln, int field, int width, int bytes, const char* src, size_t per_msg, size_t n, char* out) {
+  const FieldOps* ops = anemoi::field_ops(field);
+  const size_t eb = elem_bytes(field), rate = size_t(width - 1);
+  const size_t elem_in = bytes ? size_t(ops->chunk) : eb;        // input bytes per absorbed element
+  const size_t unit = rate * elem_in, per_msg_bytes = bytes ? per_msg : per_msg * eb;
+  size_t seg_bytes = segment_target_bytes() / n / unit * unit;
+  if (seg_bytes < unit) seg_bytes = unit;
+  const size_t nseg = (per_msg_bytes + seg_bytes - 1) / seg_bytes;
+  PermConsts pc;
+  int rc = get_consts(field, width, &pc);
+  if (!rc) rc = ln.pipeline_streams();
+  if (!rc) rc = ln.scratch[0].reserve(n * width * eb);   // carried sponge state
+  if (!rc) rc = ln.scratch[1].reserve(n * eb);           // digests
+  for (int s = 0; !rc && s < rt::kSlots; s++) {
+    rc = ln.slot[s].d_in.reserve(n * seg_bytes);
+    if (!rc) rc = ln.slot[s].p_in.reserve(n * seg_bytes);
+  }
+  if (rc) return rc;
+  for (size_t c = 0; c < nseg; c++) {
+    rt::Slot& sl = ln.slot[c % rt::kSlots];
+    const size_t off = c * seg_bytes, len = c + 1 == nseg ? per_msg_bytes - off : seg_bytes;
+    // the slot's pinned buffer is free once its previous copy-in has completed, its device buffer once the
+    // kernel that read it has: the first is waited for here, the second is a stream dependency
+    if (c >= size_t(rt::kSlots)) {
+      HIP_TRY(hipEventSynchronize(sl.e_in));
+      HIP_TRY(hipStreamWaitEvent(ln.s_in, sl.e_k, 0));
+    }
+    char* stage = (char*)sl.p_in.p;
+    for (size_t i = 0; i < n; i++) memcpy(stage + i * len, src + i * per_msg_bytes + off, len);   // strided gather
+    HIP_TRY(hipMemcpyAsync(sl.d_in.p, stage, n * len, hipMemcpyHostToDevice, ln.s_in));
+    HIP_TRY(hipEventRecord(sl.e_in, ln.s_in));
+    HIP_TRY(hipStreamWaitEvent(ln.s_k, sl.e_in, 0));
+    anemoi::SpongeSeg seg{(uint32_t*)ln.scratch[0].p, off / elem_in, per_msg, c == 0 ? 1 : 0, c + 1 == nseg ? 1 : 0};
+    // segments of the same messages depend on each other through the state: one kernel stream, in order
+    HIP_TRY(ops->sponge_seg(width, bytes, sl.d_in.p, bytes ? len : len / eb, n, ln.scratch[1].p, pc, seg, ln.s_k));
+    HIP_TRY(hipEventRecord(sl.e_k, ln.s_k));
+  }
+  HIP_TRY(hipMemcpyAsync(out, ln.scratch[1].p, n * eb, hipMemcpyDeviceToHost, ln.s_k));
+  HIP_TRY(hipStreamSynchronize(ln.s_k));
+  return ANEMOI_OK;
+}
+
+// Host-pointer sponge batch: by message chunks (rt::host_batch) or, for few long messages, by segments.
+int sponge_host(int field, int width, int bytes, const void* src, size_t per_msg, size_t n, uint64_t* out, int device) {
+  const FieldOps* ops = anemoi::field_ops(field);
+  const size_t eb = elem_bytes(field);
+  const size_t elem_in = bytes ? size_t(ops->chunk) : eb, unit = size_t(width - 1) * elem_in;
+  const size_t per_msg_bytes = bytes ? per_msg : per_msg * eb;
+  static const uint64_t dummy[2] = {0, 0};
+  if (!per_msg) src = dummy;
+  return rt::for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
+    if (count == 0) return ANEMOI_OK;
+    return with_lane(dev, [&](Lane& ln) -> int {
+      const char* in = (const char*)src + first * per_msg_bytes;
+      char* o = (char*)out + first * eb;
+      const size_t quantum = quantum_of(field, anemoi::kKindSponge, width, dev);
+      if (count < 2 * quantum && want_segments(count, per_msg_bytes, unit))
+        return sponge_segments(ln, field, width, bytes, in, per_msg, count, o);
+      return rt::pipeline(ln, count, in, per_msg_bytes, o, eb, quantum, [&](void* i, void* d, size_t cnt, hipStream_t s) {
+        return bytes ? anemoi_hash_bytes_dev(field, width, i, per_msg, cnt, d, s)
+                     : anemoi_hash_field_dev(field, width, i, per_msg, cnt, d, s);
+      });
+    });
+  });
+}
+
 // One level of arity-4 path verification: states[i] = the 4 children of item i's next node = its current
 // node at slot (index >> 2 level) & 3, the path's 3 siblings of that level in the other slots (child order).
 // Pure data movement, `quads` uint4 per element; one thread per (item, child, quad).
@@ -649,14 +739,8 @@ int anemoi_hash_field_batch(int field, int width, const uint64_t* elems, size_t 
   int rc = check_instance(field, width);
   if (rc) return rc;
   if (n && (!out || (elems_per_msg && !elems))) return ANEMOI_ERR_ARG;
-  const size_t eb = elem_bytes(field);
-  static const uint64_t dummy[2] = {0, 0};
-  return rt::host_batch(
-      device, n, elems_per_msg ? (const void*)elems : (const void*)dummy, eb * elems_per_msg, out, eb,
-      [&](int dev) { return quantum_of(field, anemoi::kKindSponge, width, dev); },
-      [&](void* i, void* o, size_t cnt, hipStream_t s) {
-        return anemoi_hash_field_dev(field, width, i, elems_per_msg, cnt, o, s);
-      });
+  if (n == 0) return ANEMOI_OK;
+  return sponge_host(field, width, 0, elems, elems_per_msg, n, out, device);
 }
 
 int anemoi_hash_bytes_batch(int field, int width, const uint8_t* msgs, size_t msg_len, size_t n, uint64_t* out,
@@ -664,13 +748,8 @@ int anemoi_hash_bytes_batch(int field, int width, const uint8_t* msgs, size_t ms
   int rc = check_instance(field, width);
   if (rc) return rc;
   if (n && (!out || (msg_len && !msgs))) return ANEMOI_ERR_ARG;
-  static const uint64_t dummy[2] = {0, 0};
-  return rt::host_batch(
-      device, n, msg_len ? (const void*)msgs : (const void*)dummy, msg_len, out, elem_bytes(field),
-      [&](int dev) { return quantum_of(field, anemoi::kKindSponge, width, dev); },
-      [&](void* i, void* o, size_t cnt, hipStream_t s) {
-        return anemoi_hash_bytes_dev(field, width, i, msg_len, cnt, o, s);
-      });
+  if (n == 0) return ANEMOI_OK;
+  return sponge_host(field, width, 1, msgs, msg_len, n, out, device);
 }
 
 int anemoi_to_montgomery(int field, const uint64_t* in, uint64_t* out, size_t count, int device) {

@@ -268,6 +268,33 @@ def test_chunked_pipeline_both_staging_modes(A, oracle, staging):
             os.environ["ANEMOI_HOST_STAGING"] = prev
 
 
+def test_sponge_fed_segment_by_segment(A, oracle, synth):
+    """Long messages from host memory are absorbed segment by segment (the state carried between launches in a
+    device buffer): force tiny segments and compare byte and element messages of lengths around the segment
+    and rate boundaries with the oracle, Anemoi-2-1 (rate 1) and 4-3 (rate 3), 4- and 6-limb fields."""
+    rng = np.random.default_rng(21)
+    prev = os.environ.get("ANEMOI_SPONGE_SEGMENT_BYTES")
+    try:
+        for field, width, n in (("bn_254", 4, 70), ("jubjub", 2, 33), ("bls12_381", 4, 40), ("bls12_377", 2, 5)):
+            fid, inst = FIELD_IDS.index(field), A.Anemoi(field, width)
+            unit = (width - 1) * inst.chunk
+            os.environ["ANEMOI_SPONGE_SEGMENT_BYTES"] = str(n * unit * 2)          # 2 rate-blocks per segment
+            seg = 2 * unit
+            for ln in (2 * seg + 1, 3 * seg, 3 * seg - 1, 3 * seg + inst.chunk, 5 * seg + 7, 10 * seg):
+                msgs = rng.integers(0, 256, size=(n, ln), dtype=np.uint8)
+                assert (inst.hash_batch(msgs) == oracle.hash_bytes_batch(fid, width, msgs, threads=8)).all(), (field, width, ln)
+            eunit = (width - 1) * inst.limbs * 8
+            os.environ["ANEMOI_SPONGE_SEGMENT_BYTES"] = str(n * eunit * 2)
+            for ne in (4 * (width - 1) + 1, 6 * (width - 1), 6 * (width - 1) + 2, 13 * (width - 1)):
+                el = synth.elements(field, 99, 0, n * ne).reshape(n, ne, inst.limbs)     # every element < p
+                assert (inst.hash_field_batch(el) == oracle.hash_field_batch(fid, width, el, threads=8)).all(), (field, width, ne)
+    finally:
+        if prev is None:
+            os.environ.pop("ANEMOI_SPONGE_SEGMENT_BYTES", None)
+        else:
+            os.environ["ANEMOI_SPONGE_SEGMENT_BYTES"] = prev
+
+
 def test_init_release_lifecycle(A, oracle):
     fid = FIELD_IDS.index("vesta")
     st = np.random.default_rng(5).integers(0, 1 << 61, size=(300, 2, 4), dtype=np.uint64)

@@ -18,7 +18,7 @@ import torch
 import anemoi_amd as A
 from anemoi_amd import synth
 
-sizes = [int(a) for a in sys.argv[1:]] or [20, 24]
+sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [20, 24]
 fid = A.field_id("bls12_381")
 inst = A.Anemoi("bls12_381", 2)
 inst.compress_batch(synth.states("bls12_381", 2, 1, 0, 4096))  # warm-up: constants, a lane
@@ -62,6 +62,42 @@ for lg in sizes:
         print("  host-pointer, staging=%-6s: %.2f ms = %.2f M/s  -> %.3f x the resident rate (first call %.1f ms)"
               % (mode, t, n / t / 1e3, resident / t, ts[0] * 1e3))
     os.environ.pop("ANEMOI_HOST_STAGING", None)
+
+# config 3 through the host-pointer entry point: 2^16 messages x 10 240 bytes (640 MiB) of pageable memory.  Too few
+# messages to cut into message chunks, so the library feeds them segment by segment (capi.hip sponge_segments).
+if "cfg3" in sys.argv or len(sys.argv) == 1:
+    cfg = synth.CFG3
+    f3 = A.field_id(cfg["field"])
+    msgs = synth.messages(cfg["seed"], 0, cfg["n"], cfg["msg_len"])
+    dig = np.empty((cfg["n"], 4), dtype=np.uint64)
+    d_m = torch.from_numpy(msgs).to("cuda:0")
+    d_o = torch.empty(cfg["n"] * 4, dtype=torch.int64, device="cuda:0")
+    res = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        assert A.lib.anemoi_hash_bytes_dev(f3, 4, d_m.data_ptr(), cfg["msg_len"], cfg["n"], d_o.data_ptr(), s.cuda_stream) == 0
+        b.record(s)
+        torch.cuda.synchronize()
+        res.append(a.elapsed_time(b))
+    resident = median(res[1:])
+    want = d_o.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    del d_m, d_o
+    print("config 3 (2^16 x 10 240 B, BN-254 4-3): device-resident kernel %.1f ms" % resident)
+    for label, env in (("segments (default)", None), ("single launch", "1099511627776")):
+        if env:
+            os.environ["ANEMOI_SPONGE_SEGMENT_BYTES"] = env   # one segment would hold everything -> single launch
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = A.lib.anemoi_hash_bytes_batch(f3, 4, msgs.ctypes.data_as(A._lib._u8p), cfg["msg_len"], cfg["n"],
+                                               dig.ctypes.data_as(A._lib._u64p), 0)
+            ts.append(time.perf_counter() - t0)
+            assert rc == 0
+        assert (dig == want).all()
+        t = median(ts[1:]) * 1e3
+        print("  host-pointer, %-18s: %.1f ms -> %.3f x the resident rate (first call %.1f ms)" % (label, t, resident / t, ts[0] * 1e3))
+    os.environ.pop("ANEMOI_SPONGE_SEGMENT_BYTES", None)
 
 # concurrent callers: latency-bound calls (48 items = one wave-cooperative launch each) from 4 threads
 sts = [synth.states("bls12_381", 2, 77 + k, 0, 48) for k in range(4)]
