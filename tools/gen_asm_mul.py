@@ -315,6 +315,66 @@ def gen_coop_mul(nl, n0inv, W=29):
     return out, clob
 
 
+def coop_qp_params(p, W=29):
+    """Quotient-pipelined form of the cooperative product (Orup 1995, delay d = 1), radix 2^W:
+    Mt = (-p^-1 mod 2^2W) p  (= -1 mod 2^2W),  Mq = (Mt + 1) / 2^2W,  n = number of W-bit digits with 4 Mt < 2^(W n)
+    raised until the limb-padded subtraction constant (all n - 1 low limbs >= 2^W) leaves room for the S-box's
+    operand growth.  A product of A, B <= 2 Mt is  = A B 2^(-W n) mod p  and  <= 2 Mt."""
+    Mp = (-pow(p, -1, 1 << (2 * W))) % (1 << (2 * W))
+    Mt = Mp * p
+    assert (Mt + 1) % (1 << (2 * W)) == 0
+    Mq = (Mt + 1) >> (2 * W)
+    n = 1
+    while (1 << (W * n)) <= 4 * Mt:
+        n += 1
+    # head room H' = 2^(W n) / (4 Mt): products stay <= 2 Mt while (A / 2Mt)(B / 2Mt) <= H'.  Subtraction pads with
+    # a multiple of p whose n - 1 low limbs are all >= 2^W - 1, i.e. ~2^(W n) / 2^W ... 2^(W n): one more digit
+    # when that would eat the head room (the 253..255-bit fields: n = 11 -> 12)
+    if (1 << (W * n)) // (4 * Mt) < (1 << 12):
+        n += 1
+    return Mt, Mq, n
+
+
+def gen_coop_mul_qp(n, W=29):
+    """Quotient-pipelined cooperative product, one asm statement.  Lane j < n holds limb j.
+    Operands: %0 = t.lo (out), %1 = t.hi (out), %2 = a, %3 = b, %4 = Mq limb of this lane, %5 = Mq limb of lane - 1
+    (Mq shifted up one lane), %6 = per-lane shift amount (W in lane 0, 63 elsewhere).
+        S_1 = a_0 B
+        for i = 1 .. n:   q_i = S_i mod 2^W ;  S_{i+1} = (S_i >> W) + a_i B + q_{i-1} Mq      (a_n = 0, q_0 = 0)
+        result = S_{n+1} + 2^W q_n Mq          (= 2^W S_{n+2} + q_{n+1} of the textbook form)
+    The quotient digit q_i is read one step before it is used, so it is off the dependent chain: per step
+    shift -> lane-shift add (2) -> multiply-add (2), with v_readlane / s_and in the shadow -- against
+    multiply-add -> readlane -> s_mul -> s_and -> multiply-add -> shift -> add (2) of gen_coop_mul."""
+    MASK = (1 << W) - 1
+    T, U = COOP_VBASE, COOP_VBASE + 2
+    TT, UU = "v[%d:%d]" % (T, T + 1), "v[%d:%d]" % (U, U + 1)
+    SA = lambda i: "s%d" % (COOP_SBASE + i)
+    SQ = lambda i: "s%d" % (COOP_SBASE + n + (i & 1))
+    dpp = "row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    out = ["s_nop 1"]
+    for i in range(n):
+        out.append("v_readlane_b32 %s, %%2, %d" % (SA(i), i))
+    out.append("s_nop 1")
+    out.append("v_mad_u64_u32 %s, vcc, %s, %%3, 0" % (TT, SA(0)))
+    for i in range(1, n + 1):
+        out.append("v_lshrrev_b64 %s, %%6, %s" % (UU, TT))
+        out.append("v_readlane_b32 %s, v%d, 0" % (SQ(i), T))
+        out.append("s_and_b32 %s, %s, 0x%x" % (SQ(i), SQ(i), MASK))
+        out.append("v_add_co_u32_dpp v%d, vcc, v%d, v%d %s" % (T, T, U, dpp))
+        out.append("v_addc_co_u32_dpp v%d, vcc, v%d, v%d, vcc %s" % (T + 1, T + 1, U + 1, dpp))
+        if i < n:
+            out.append("v_mad_u64_u32 %s, vcc, %s, %%3, %s" % (TT, SA(i), TT))
+        if i >= 2:
+            out.append("v_mad_u64_u32 %s, vcc, %s, %%4, %s" % (TT, SQ(i - 1), TT))
+    out.append("v_mad_u64_u32 %s, vcc, %s, %%5, %s" % (TT, SQ(n), TT))
+    out.append("v_mov_b32 %%0, v%d" % T)
+    out.append("v_mov_b32 %%1, v%d" % (T + 1))
+    out.append("s_nop 1")
+    clob = (["v%d" % r for r in range(COOP_VBASE, COOP_VBASE + 4)] +
+            ["s%d" % (COOP_SBASE + i) for i in range(n + 2)] + ["vcc"])
+    return out, clob
+
+
 def emit(name, lines, outs, ins, clob):
     body = "\n".join('        "%s\\n\\t"' % l for l in lines)
     return ("    asm volatile(\n%s\n        : %s\n        : %s\n        : %s);\n"
@@ -364,6 +424,26 @@ def main():
         h.append("  __device__ static __forceinline__ uint64_t mul(uint32_t a, uint32_t b, uint32_t pl, uint32_t sh) {")
         h.append("    uint32_t lo, hi;")
         h.append(emit("coop", co, ['"=&v"(lo)', '"=&v"(hi)'], ['"v"(a)', '"v"(b)', '"v"(pl)', '"v"(sh)'], co_clob))
+        h.append("    return ((uint64_t)hi << 32) | lo;")
+        h.append("  }")
+        h.append("};")
+    # Quotient-pipelined cooperative product (Orup, delay 1; gen_coop_mul_qp): measured and NOT adopted -- a lone
+    # wavefront issues one instruction per ~7 cycles whatever the dependences, so a product's latency is its
+    # instruction count, and the pipelined scan needs 2-3 more steps (profiles/r02/ubench_coop_scan_latency.txt:
+    # BLS12-381 384 -> 364 ns per product, Jubjub 255 -> 279 ns).  ANEMOI_GEN_COOP_QP=1 emits it for
+    # tools/ubench/coop_scan_latency.hip.
+    h.append("template <int FIELD> struct AsmCoopQP;")
+    for fid, name in enumerate(FIELD_IDS if os.environ.get("ANEMOI_GEN_COOP_QP") == "1" else []):
+        p = int(params[name]["modulus"])
+        Mt, Mq, n = coop_qp_params(p)
+        co, co_clob = gen_coop_mul_qp(n)
+        h.append("// %s: %d limbs / steps, %d instructions" % (name, n, len(co)))
+        h.append("template <> struct AsmCoopQP<%d> {" % fid)
+        h.append("  static constexpr int NX = %d;" % n)
+        h.append("  __device__ static __forceinline__ uint64_t mul(uint32_t a, uint32_t b, uint32_t mq, uint32_t mqup, uint32_t sh) {")
+        h.append("    uint32_t lo, hi;")
+        h.append(emit("coopqp", co, ['"=&v"(lo)', '"=&v"(hi)'],
+                      ['"v"(a)', '"v"(b)', '"v"(mq)', '"v"(mqup)', '"v"(sh)'], co_clob))
         h.append("    return ((uint64_t)hi << 32) | lo;")
         h.append("  }")
         h.append("};")
