@@ -121,6 +121,20 @@ def device_count():
     return n
 
 
+def init(field, width, device=ALL_DEVICES):
+    """Upload the constant tables of (field, width) and create one lane ahead of time (anemoi_init)."""
+    rc = lib.anemoi_init(device, field_id(field), width)
+    if rc != 0:
+        raise AnemoiError(rc, lib.anemoi_last_error().decode())
+
+
+def release(device=ALL_DEVICES):
+    """Free everything the library holds on `device` (anemoi_release); it re-initialises lazily afterwards."""
+    rc = lib.anemoi_release(device)
+    if rc != 0:
+        raise AnemoiError(rc, lib.anemoi_last_error().decode())
+
+
 def field_id(field):
     if isinstance(field, str):
         fid = lib.anemoi_field_id(field.encode())

@@ -49,6 +49,7 @@ constexpr int kSlots = 3;                         // chunks in flight per lane
 constexpr int kScratch = 6;                       // ad-hoc device buffers per lane (Merkle drivers, verification)
 constexpr size_t kChunkTargetBytes = 24u << 20;   // input bytes per chunk, rounded to the kernel's quantum
 constexpr size_t kRetainBytes = 256u << 20;       // buffers above this are returned to HIP when a lane is released
+constexpr size_t kMaxIdleLanes = 8;               // lanes kept per device between calls (each holds ~100 MB pinned + device)
 
 struct DeviceGuard {  // restores the caller's current device
   int prev = -1;
@@ -258,9 +259,18 @@ inline void release_lane(Lane* ln) {
   if (!ln) return;
   ln->trim();
   DeviceCtx& c = g_ctx[ln->dev];
-  std::lock_guard<std::mutex> lock(c.mu);
-  c.idle.push_back(ln);
-  c.lanes_out--;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.lanes_out--;
+    if (c.idle.size() < kMaxIdleLanes) {
+      c.idle.push_back(ln);
+      return;
+    }
+  }
+  // a burst of concurrent callers is over: do not sit on its staging memory for ever
+  DeviceGuard guard;
+  if (hipSetDevice(ln->dev) == hipSuccess) ln->destroy();
+  delete ln;
 }
 
 struct LaneGuard {

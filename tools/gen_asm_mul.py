@@ -30,6 +30,11 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELD_IDS = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
 TMP_BASE = int(os.environ.get("ANEMOI_ASM_TMP_BASE", "100"))  # clobbered VGPRs start here (even: the 64-bit accumulator is 2-aligned)
+TMP_BASE9 = int(os.environ.get("ANEMOI_ASM_TMP_BASE9", str(TMP_BASE)))  # the same for the 9-limb fields (A/B of their occupancy)
+
+
+def tmp_base(nl):
+    return TMP_BASE if nl >= 13 else TMP_BASE9
 SGPR_BASE = 60      # clobbered SGPRs of the multiplication
 CHAINS = int(os.environ.get("ANEMOI_ASM_CHAINS", "1"))   # independent multiply-add chains per column (see Column.mads)
 CAP = 1 << 64
@@ -169,6 +174,7 @@ def gen_sqr(nl, plimbs, n0inv, W, p=None):
     amax = [MASK] * nl
     if W >= 30:
         amax[nl - 1] = top_limb_bound(p, W, nl, SQR_A_MULT)
+    TMP_BASE = tmp_base(nl)
     acc = TMP_BASE                 # v[acc:acc+1]
     a2 = TMP_BASE + 2              # nl regs
     m = a2 + nl                    # nl regs
@@ -226,6 +232,7 @@ def gen_mul(nl, plimbs, n0inv, W, p=None):
     bmax = [MASK] * nl
     if W >= 30:
         bmax[nl - 1] = top_limb_bound(p, W, nl, MUL_B_MULT)
+    TMP_BASE = tmp_base(nl)
     acc = TMP_BASE
     m = TMP_BASE + 2
     treg = (m + nl + 1) & ~1
