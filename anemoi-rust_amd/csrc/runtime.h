@@ -388,15 +388,23 @@ int pipeline(Lane& ln, size_t n, const char* in, size_t ipi, char* out, size_t o
   const bool inplace = !d_dst && (const void*)in == (const void*)out;
   const host::ChunkPlan cp = host::plan_chunks(n, quantum, ipi, kChunkTargetBytes);
   if (cp.chunks == 0) return ANEMOI_OK;
-  const bool staged = staging_mode() == 1;
+  bool staged = staging_mode() == 1;
+  // Pinned staging is an optimisation: when the host cannot pin that much (locked-memory limits), fall back to
+  // copying straight from the caller's memory instead of failing the call.
+  auto pin = [&](Slot& sl, size_t in_bytes, size_t out_bytes) {
+    if (!staged) return;
+    if (sl.p_in.reserve(in_bytes) || (!d_dst && sl.p_out.reserve(out_bytes))) {
+      staged = false;
+      for (auto& s : ln.slot) s.p_in.release(), s.p_out.release();
+    }
+  };
   if (cp.chunks == 1) {
     // one chunk: copy-in, kernel, copy-out in order on the lane's kernel stream
     Slot& sl = ln.slot[0];
     int rc = sl.d_in.reserve(n * ipi);
     if (!rc && !inplace && !d_dst) rc = sl.d_out.reserve(n * opi);
-    if (!rc && staged) rc = sl.p_in.reserve(n * ipi);
-    if (!rc && staged && !d_dst) rc = sl.p_out.reserve(n * opi);
     if (rc) return rc;
+    pin(sl, n * ipi, n * opi);
     if (staged) memcpy(sl.p_in.p, in, n * ipi);
     HIP_TRY(hipMemcpyAsync(sl.d_in.p, staged ? (const void*)sl.p_in.p : (const void*)in, n * ipi, hipMemcpyHostToDevice,
                            ln.s_k));
@@ -415,9 +423,8 @@ int pipeline(Lane& ln, size_t n, const char* in, size_t ipi, char* out, size_t o
     Slot& sl = ln.slot[s];
     int rc = sl.d_in.reserve(cp.chunk_items * ipi);
     if (!rc && !inplace && !d_dst) rc = sl.d_out.reserve(cp.chunk_items * opi);
-    if (!rc && staged) rc = sl.p_in.reserve(cp.chunk_items * ipi);
-    if (!rc && staged && !d_dst) rc = sl.p_out.reserve(cp.chunk_items * opi);
     if (rc) return rc;
+    pin(sl, cp.chunk_items * ipi, cp.chunk_items * opi);
   }
   auto first_of = [&](size_t c) { return c * cp.chunk_items; };
   auto count_of = [&](size_t c) { return c + 1 == cp.chunks ? n - first_of(c) : cp.chunk_items; };
