@@ -74,6 +74,8 @@ _SIGS = {
     "anemoi_merge_batch": ([_int, _u64p, _u64p, _sz, _int], _int),
     "anemoi_hash_field_batch": ([_int, _int, _u64p, _sz, _sz, _u64p, _int], _int),
     "anemoi_hash_bytes_batch": ([_int, _int, _u8p, _sz, _sz, _u64p, _int], _int),
+    "anemoi_hash_bytes_ragged_batch": ([_int, _int, _u8p, _u64p, _sz, _u64p, _int], _int),
+    "anemoi_hash_bytes_ragged_dev": ([_int, _int, _vp, _vp, _sz, _vp, _vp], _int),
     "anemoi_merkle_root": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
     "anemoi_merkle_tree": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
     "anemoi_merkle_path": ([_int, _u64p, ctypes.c_uint, _sz, _u64p], _int),
@@ -269,6 +271,17 @@ class Anemoi:
         ptr = _p8(m) if m.size else None
         _check(lib.anemoi_hash_bytes_batch(self.field, self.width, ptr, m.shape[1], m.shape[0], _p64(out),
                                            self.device))
+        return out
+
+    def hash_ragged(self, messages):
+        """Sponge::hash of each of `messages` (a sequence of bytes-like objects of any lengths) in one launch."""
+        lens = [len(m) for m in messages]
+        offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens, dtype=np.uint64)
+        blob = np.frombuffer(b"".join(bytes(m) for m in messages), dtype=np.uint8)
+        out = np.empty((len(lens), self.limbs), dtype=np.uint64)
+        _check(lib.anemoi_hash_bytes_ragged_batch(self.field, self.width, _p8(blob) if blob.size else None, _p64(offs),
+                                                  len(lens), _p64(out) if len(lens) else None, self.device))
         return out
 
     def merkle_root(self, leaves, depth):

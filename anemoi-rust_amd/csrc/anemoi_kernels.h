@@ -441,6 +441,106 @@ ANEMOI_KERNEL void k_sponge_pair(const void* __restrict__ src, size_t per_msg, s
   block_store<A::NABI / 4>(lds, out, st0, cnt);
 }
 
+// ---- sponge over messages of DIFFERENT lengths (Sponge::hash on a ragged batch) ----------------------------
+// Message i = bytes [off[i], off[i+1]) of `msgs`.  Every lane walks its own message; the wavefront runs as many
+// rate-blocks as its longest message needs.  A rate-block is: absorb up to RATE elements (a message's last
+// block may be short: the cells it does not reach get nothing, which is what the reference's
+// "permute when i == RATE or at the last element" does), then permute.  The permutation is executed by all
+// lanes in every block (wave-uniform control flow around the big inlined body; the lane pairs of the 4-3
+// kernel need each other in the linear layer); a lane whose message has ended latches its digest after its
+// own last block and lets its state run on unobserved.  Callers that care about throughput sort the batch
+// by length: a wavefront costs what its longest message costs.
+template <class T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int d = 32; d; d >>= 1) {
+    const T o = __shfl_xor(v, d);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+template <int FIELD>
+ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off, size_t n,
+                                   uint4* __restrict__ out, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using A = ArithFor<FIELD>;
+  constexpr int WIN = KernelCfg<F::N>::WIN;  // Anemoi-2-1: RATE = 1, a block is one element
+  extern __shared__ uint4 lds[];
+  const size_t blk0 = size_t(blockIdx.x) * kBlock;
+  const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
+  const size_t item = blk0 + (threadIdx.x < cnt ? threadIdx.x : 0);  // idle lanes redo item blk0
+  const uint64_t o0 = off[item], len = off[item + 1] - o0;
+  const uint8_t* msg = msgs + o0;
+  const size_t num = (len + F::kChunk - 1) / F::kChunk;  // RATE = 1: no padding element ever
+  const unsigned blocks = (unsigned)num, bmax = wave_max(blocks);
+  typename A::Fe st[2], dig;
+  A::set_zero(st[0]);
+  A::set_zero(st[1]);
+  A::set_zero(dig);  // the empty message hashes to state[0] of the zero state
+  const LdsTable<A> tab = make_table<A>(lds);
+#pragma nounroll
+  for (unsigned b = 0; b < bmax; b++) {
+    if (b < blocks) {
+      typename A::Fe el;
+      sponge_element<F, A, true>(el, msg, b, 0, num, len);
+      A::add(st[0], st[0], el);
+    }
+    permutation<F, A, 2, WIN>(st, pc, tab);
+    fe_select<A>(dig, b + 1 == blocks, st[0], dig);
+  }
+  __syncthreads();
+  lds_put<A>(lds, threadIdx.x, dig);
+  block_store<A::NABI / 4>(lds, out, blk0, cnt);
+}
+
+template <int FIELD>
+ANEMOI_KERNEL void k_sponge_ragged_pair(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off, size_t n,
+                                        uint4* __restrict__ out, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using A = ArithFor<FIELD>;
+  constexpr int WIN = KernelCfg<F::N>::WIN, RATE = 3;
+  extern __shared__ uint4 lds[];
+  const size_t st0 = size_t(blockIdx.x) * kPairStates;
+  const int cnt = n - st0 < size_t(kPairStates) ? int(n - st0) : kPairStates;
+  const bool odd = threadIdx.x & 1;
+  const int s = threadIdx.x >> 1;
+  const size_t item = st0 + (s < cnt ? s : 0);  // idle lane pairs redo item st0
+  const uint64_t o0 = off[item], len = off[item + 1] - o0;
+  const uint8_t* msg = msgs + o0;
+  const size_t num = (len + F::kChunk - 1) / F::kChunk;
+  const size_t total = num + (num % RATE == 0 ? 0 : 1);  // + the padding element 1
+  const unsigned blocks = (unsigned)((total + RATE - 1) / RATE), bmax = wave_max(blocks);
+  typename A::Fe x, y, dig;
+  A::set_zero(x);
+  A::set_zero(y);
+  A::set_zero(dig);
+  const LdsTable<A> tab = make_table<A>(lds);
+#pragma nounroll
+  for (unsigned b = 0; b < bmax; b++) {
+    // state[0] -> even.x, state[1] -> odd.x, state[2] -> even.y; both lanes of a pair see the same message
+    static_for<0, RATE>([&](auto r) {
+      const size_t e = size_t(b) * RATE + r;
+      if (e < total) {
+        typename A::Fe el, t;
+        sponge_element<F, A, true>(el, msg, e, 0, num, len);
+        if (r < 2) {
+          A::add(t, x, el);
+          fe_select<A>(x, odd == (r == 1), t, x);
+        } else {
+          A::add(t, y, el);
+          fe_select<A>(y, !odd, t, y);
+        }
+      }
+    });
+    permutation_pair<F, A, WIN>(x, y, odd, pc, tab);
+    fe_select<A>(dig, b + 1 == blocks, x, dig);
+  }
+  __syncthreads();
+  lds_put<A>(lds, odd ? kPairStates + s : s, dig);  // digest = state[0] = the even lane's x
+  block_store<A::NABI / 4>(lds, out, st0, cnt);
+}
+
 // Merkle authentication: lane i hashes leaf i up its path (depth sibling digests, bottom-up) with
 // the 2-1 instance's merge (= Jive compress of [left, right], anemoi_2_1/hasher.rs:87-92) and writes
 // the recomputed root; bit l of index[i] says whether the node is the right child at level l.
@@ -621,6 +721,9 @@ struct FieldOps {
   // one segment of every message (SpongeSeg): per_msg = this launch's bytes / elements per message
   hipError_t (*sponge_seg)(int width, int bytes, const void* d_src, size_t per_msg, size_t n, void* d_out, PermConsts pc,
                            SpongeSeg seg, hipStream_t s);
+  // messages of different lengths: message i = bytes [off[i], off[i+1]) of d_msgs
+  hipError_t (*sponge_ragged)(int width, const void* d_msgs, const void* d_off, size_t n, void* d_out, PermConsts pc,
+                              hipStream_t s);
   hipError_t (*mont_convert)(int to, const void* d_in, void* d_out, size_t count, hipStream_t s);
   hipError_t (*merkle_climb)(const void* d_leaves, const void* d_index, const void* d_paths, unsigned depth, size_t n,
                              void* d_out, PermConsts pc, hipStream_t s);
@@ -737,6 +840,18 @@ struct Launch {
     return sponge_seg(width, bytes, src, per_msg, n, out, pc, SpongeSeg{nullptr, 0, per_msg, 1, 1}, s);
   }
 
+  static hipError_t sponge_ragged(int width, const void* msgs, const void* off, size_t n, void* out, PermConsts pc,
+                                  hipStream_t s) {
+    if (!n) return hipSuccess;
+    if (width == 2)
+      k_sponge_ragged<FIELD><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>((const uint8_t*)msgs, (const uint64_t*)off,
+                                                                                n, (uint4*)out, pc);
+    else
+      k_sponge_ragged_pair<FIELD><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(
+          (const uint8_t*)msgs, (const uint64_t*)off, n, (uint4*)out, pc);
+    return hipGetLastError();
+  }
+
   static hipError_t mont_convert(int to, const void* in, void* out, size_t count, hipStream_t s) {
     if (!count) return hipSuccess;
     k_mont_convert<FIELD><<<grid_for(count), kBlock, size_t(N) * 4 * kBlock, s>>>((const uint4*)in, (uint4*)out, count, to);
@@ -811,7 +926,7 @@ struct Launch {
 
   static const FieldOps* ops() {
     static const FieldOps o{F::L64,       F::kChunk,    F::kRounds21,        F::kRounds43, F::kG, F::kAlpha, F::kName,
-                            host_consts,  permutation,  jive,                sponge,       sponge_seg,   mont_convert,
+                            host_consts,  permutation,  jive,                sponge,       sponge_seg,   sponge_ragged, mont_convert,
                             merkle_climb, generic_permutation, generic_jive, generic_sponge, exp_alpha, wave_items};
     return &o;
   }

@@ -637,6 +637,17 @@ int anemoi_hash_bytes_dev(int field, int width, const void* d_msgs, size_t msg_l
   return ANEMOI_OK;
 }
 
+int anemoi_hash_bytes_ragged_dev(int field, int width, const void* d_msgs, const void* d_offsets, size_t n, void* d_out,
+                                 void* stream) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && (!d_out || !d_offsets || !d_msgs)) return ANEMOI_ERR_ARG;
+  PermConsts pc;
+  if ((rc = get_consts(field, width, &pc))) return rc;
+  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, d_msgs, d_offsets, n, d_out, pc, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
 int anemoi_merkle_root_dev(int field, const void* d_leaves, unsigned depth, void* d_scratch, void* d_root,
                            void* stream) {
   int rc = check_instance(field, 2);
@@ -750,6 +761,41 @@ int anemoi_hash_bytes_batch(int field, int width, const uint8_t* msgs, size_t ms
   if (n && (!out || (msg_len && !msgs))) return ANEMOI_ERR_ARG;
   if (n == 0) return ANEMOI_OK;
   return sponge_host(field, width, 1, msgs, msg_len, n, out, device);
+}
+
+int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t* msgs, const uint64_t* offsets, size_t n,
+                                   uint64_t* out, int device) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && (!out || !offsets)) return ANEMOI_ERR_ARG;
+  if (n == 0) return ANEMOI_OK;
+  for (size_t i = 0; i < n; i++)
+    if (offsets[i + 1] < offsets[i]) return ANEMOI_ERR_ARG;  // offsets must be non-decreasing
+  if (offsets[n] > offsets[0] && !msgs) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(field);
+  static const uint8_t dummy[16] = {0};
+  return rt::for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
+    if (!count) return ANEMOI_OK;
+    return with_lane(dev, [&](Lane& ln) -> int {
+      const uint64_t base = offsets[first], bytes = offsets[first + count] - base;
+      std::vector<uint64_t> rel(count + 1);
+      for (size_t i = 0; i <= count; i++) rel[i] = offsets[first + i] - base;
+      rt::Buf &dm = ln.scratch[0], &dof = ln.scratch[1], &dd = ln.scratch[2];
+      int r = dm.reserve(bytes + 16);
+      if (!r) r = dof.reserve((count + 1) * 8);
+      if (!r) r = dd.reserve(count * eb);
+      if (r) return r;
+      hipStream_t s = ln.s_k;
+      HIP_TRY(hipMemcpyAsync(dm.p, bytes ? (const void*)(msgs + base) : (const void*)dummy, bytes ? bytes : 16,
+                             hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(dof.p, rel.data(), (count + 1) * 8, hipMemcpyHostToDevice, s));
+      r = anemoi_hash_bytes_ragged_dev(field, width, dm.p, dof.p, count, dd.p, s);
+      if (r) return r;
+      HIP_TRY(hipMemcpyAsync((char*)out + first * eb, dd.p, count * eb, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));  // `rel` must outlive the copy-in
+      return ANEMOI_OK;
+    });
+  });
 }
 
 int anemoi_to_montgomery(int field, const uint64_t* in, uint64_t* out, size_t count, int device) {

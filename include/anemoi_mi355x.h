@@ -128,6 +128,12 @@ int anemoi_hash_field_batch(int field, int width, const uint64_t *elems, size_t 
 int anemoi_hash_bytes_batch(int field, int width, const uint8_t *msgs, size_t msg_len, size_t n, uint64_t *out,
                             int device);
 
+/* Sponge::hash on n messages of DIFFERENT lengths: message i = bytes [offsets[i], offsets[i+1]) of `msgs`
+ * (n + 1 non-decreasing byte offsets; an empty message hashes to the digest of the zero state, as the
+ * reference's hash(b"") does).  A wavefront costs what its longest message costs: sort by length for speed. */
+int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t *msgs, const uint64_t *offsets, size_t n,
+                                   uint64_t *out, int device);
+
 /* Root of the binary Merkle tree over 2^depth leaf digests built with the 2-1 instance's merge,
  * level by level (depth 0 returns the leaf; depth <= 30).  With ANEMOI_ALL_DEVICES each GPU
  * builds a contiguous subtree and the top log2(#GPUs) levels finish on the first device. */
@@ -212,6 +218,9 @@ int anemoi_hash_field_dev(int field, int width, const void *d_elems, size_t elem
                           void *stream);
 int anemoi_hash_bytes_dev(int field, int width, const void *d_msgs, size_t msg_len, size_t n, void *d_out,
                           void *stream);
+/* d_offsets: n + 1 uint64 byte offsets into d_msgs (see anemoi_hash_bytes_ragged_batch). */
+int anemoi_hash_bytes_ragged_dev(int field, int width, const void *d_msgs, const void *d_offsets, size_t n, void *d_out,
+                                 void *stream);
 /* d_scratch: at least 2^depth elements; d_root: 1 element; d_leaves is not modified. */
 int anemoi_merkle_root_dev(int field, const void *d_leaves, unsigned depth, void *d_scratch, void *d_root,
                            void *stream);

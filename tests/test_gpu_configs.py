@@ -295,6 +295,33 @@ def test_sponge_fed_segment_by_segment(A, oracle, synth):
             os.environ["ANEMOI_SPONGE_SEGMENT_BYTES"] = prev
 
 
+def test_ragged_batch_of_messages_of_different_lengths(A, oracle):
+    """anemoi_hash_bytes_ragged_batch: one launch over messages of different lengths (empty, 1 byte, around the
+    chunk and rate-block boundaries, long), both widths, 4- and 6-limb fields, also sharded; every digest equals
+    the oracle's hash of that message alone."""
+    rng = np.random.default_rng(31)
+    for field, width in (("bn_254", 4), ("jubjub", 2), ("bls12_381", 4), ("bls12_381", 2), ("ed_on_bls12_377", 4)):
+        fid, inst = FIELD_IDS.index(field), A.Anemoi(field, width)
+        c, r = inst.chunk, width - 1
+        lens = [0, 1, c - 1, c, c + 1, r * c - 1, r * c, r * c + 1, 2 * r * c, 2 * r * c + c, 7 * c + 3, 400, 0, 5]
+        lens += [int(v) for v in rng.integers(0, 300, size=140)]
+        msgs = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for n in lens]
+        got = inst.hash_ragged(msgs)
+        for i, m in enumerate(msgs):
+            assert (got[i] == oracle.hash_bytes(fid, width, m)).all(), (field, width, lens[i])
+        with virtual_devices(3):
+            many = A.Anemoi(field, width, device=A.ALL_DEVICES).hash_ragged(msgs)
+        assert (many == got).all()
+        assert (inst.hash_ragged([b""])[0] == 0).all() and len(inst.hash_ragged([])) == 0
+    # decreasing offsets are rejected before any device work
+    offs = np.array([0, 10, 5], dtype=np.uint64)
+    blob = np.zeros(16, dtype=np.uint8)
+    out = np.zeros((2, 4), dtype=np.uint64)
+    from anemoi_amd import _lib
+    assert A.lib.anemoi_hash_bytes_ragged_batch(4, 2, blob.ctypes.data_as(_lib._u8p), offs.ctypes.data_as(_lib._u64p), 2,
+                                                out.ctypes.data_as(_lib._u64p), 0) == -3
+
+
 def test_init_release_lifecycle(A, oracle):
     fid = FIELD_IDS.index("vesta")
     st = np.random.default_rng(5).integers(0, 1 << 61, size=(300, 2, 4), dtype=np.uint64)
