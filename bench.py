@@ -259,7 +259,7 @@ def main():
         # (profiles/rNN/pmc_k_jive.json): counters cannot be read from inside the process.  It is reported
         # only if that profile was taken from the kernel sources being run.
         csrc = buildinfo.csrc_sha256()
-        traffic, prof_src, prof_clock, stale = None, None, None, None
+        traffic, prof_src, prof_clock, stale, valu_per_item = None, None, None, None, None
         try:
             prof_dirs = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles"))
                                if d.startswith("r") and os.path.exists(os.path.join(ROOT, "profiles", d, "pmc_k_jive.json")))
@@ -268,6 +268,7 @@ def main():
             stale = pmc.get("csrc_sha256") != csrc
             if not stale:
                 prof_clock = pmc["derived"]["clock_GHz"]
+                valu_per_item = pmc["derived"]["valu_wave_instructions_per_wavefront"]  # = per lane = per compression
                 if lg == 20:
                     traffic = pmc["derived"]["hbm_traffic_bytes_per_launch"]
         except Exception:
@@ -303,6 +304,12 @@ def main():
                     "peak_lane_mad_per_s": SIMDS * LANES_PER_CLK * clock * 1e9, "clock_GHz": clock,
                     "clock_source": "GRBM_GUI_ACTIVE of the committed profile" if prof_clock else "nominal",
                     "frac": lane_mad_per_s / (SIMDS * LANES_PER_CLK * clock * 1e9),
+                    # every VALU instruction of any class occupies a 16-lane SIMD for 4 cycles per wavefront: all VALU
+                    # lane-instructions (SQ_INSTS_VALU of the committed profile) against the same peak -- ~1.0 means the
+                    # vector ALUs never idle and only a lower instruction count can raise `value`
+                    "valu_instr_per_item": valu_per_item,
+                    "valu_util": (valu_per_item * n / (kernel_ms * 1e-3) / (SIMDS * LANES_PER_CLK * clock * 1e9))
+                    if valu_per_item else None,
                     "note": "v_mad_u64_u32 lane-operations per second (count per compression from the generated assembly: "
                             "21 rounds x (381 squarings x 260 + 101 multiplications x 338) + 5 x 338) against 1024 SIMDs x "
                             "16 lanes per clock; the path is VALU-issue bound, see DESIGN.md"},
