@@ -11,8 +11,9 @@ out="gpurun_out/prof_${tag}"
 mkdir -p "$out"
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline"
-python bench.py > "$out/bench_n1.json" 2> "$out/bench_n1.err" || exit 1
-tail -c 400 "$out/bench_n1.json"; echo
+# a first bench line for the summariser (batch size, kernel time); the judged line is taken at the end, after the
+# fresh counter summary is in place, so that its roofline.traffic / alu.valu_util refer to THIS build
+python bench.py --no-cpu-baseline --steps 2 > "$out/bench_n1.json" 2> "$out/bench_n1.err" || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- $BENCH > "$out/stats.log" 2>&1 || exit 1
 PMC="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -o run -- $PMC > "$out/pmc_fetch.log" 2>&1 || exit 1
@@ -20,3 +21,6 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv \
     -d "$out/pmc_sq" -o run -- $PMC > "$out/pmc_sq.log" 2>&1 || exit 1
 python tools/summarize_profiles.py "$out" || exit 1
+mkdir -p "profiles/${tag}" && cp "$out/pmc_k_jive.json" "profiles/${tag}/pmc_k_jive.json"
+python bench.py > "$out/bench_n1.json" 2> "$out/bench_n1.err" || exit 1
+tail -c 600 "$out/bench_n1.json"; echo
