@@ -41,16 +41,29 @@ def bls12_381_limb_layout():
     return best
 
 
+def _field0_array(hdr, name):
+    blk = hdr[hdr.index("struct FieldC<0>"):]
+    m = re.search(r"%s\[[^\]]*\]\s*=\s*\{([^}]*)\}" % name, blk)
+    return [int(v, 0) for v in m.group(1).replace("\n", " ").split(",") if v.strip()]
+
+
 def bls12_381_products_per_round():
-    """(squarings, multiplications) one round of k_jive<bls12_381> executes: the S-box's window schedule
-    (field_consts_gen.h, window ANEMOI_WIN = 3) + x^2 and the table + its two y^2 + the two settle() products."""
+    """(squarings, multiplications) one round of k_jive<bls12_381> executes: the S-box's exponentiation -- window 3
+    plus the extra digits held in VGPRs when the field has them (field_consts_gen.h kXSched + the digits' build
+    programmes), else the plain kW3Sched -- with x^2 and the table build, + its two y^2 + the two settle() products."""
     hdr = open(os.path.join(CSRC, "field_consts_gen.h")).read()
     blk = hdr[hdr.index("struct FieldC<0>"):]
-    m = re.search(r"kW3Sched\[[^\]]*\]\s*=\s*\{([^}]*)\}", blk)
-    vals = [int(v, 0) for v in m.group(1).replace("\n", " ").split(",") if v.strip()]
+    nx = int(re.search(r"kXDigits = (\d+)", blk).group(1))
+    if nx:
+        vals = _field0_array(hdr, "kXSched")
+        ops, args = _field0_array(hdr, "kXProgOp"), _field0_array(hdr, "kXProgArg")
+        build_sq = sum(a for o, a in zip(ops, args) if o == 1)
+        build_mu = sum(1 for o in ops if o == 2)
+    else:
+        vals, build_sq, build_mu = _field0_array(hdr, "kW3Sched"), 0, 0
     pairs = list(zip(vals[0::2], vals[1::2]))
-    sq = sum(s for s, _ in pairs) + 1 + 2            # chain + x^2 + the two y^2
-    mu = sum(1 for _, op in pairs if op != 255 and op != 253) + 3 + 2   # chain + x^3, x^5, x^7 + 2 settles
+    sq = sum(s for s, _ in pairs) + 1 + build_sq + 2            # chain + x^2 + digit builds + the two y^2
+    mu = sum(1 for _, op in pairs if op not in (255, 253)) + 3 + build_mu + 2   # chain + x^3, x^5, x^7 + builds + 2 settles
     return sq, mu
 
 

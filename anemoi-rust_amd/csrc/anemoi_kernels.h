@@ -53,9 +53,15 @@ struct KernelCfg {
   static constexpr int WIN = ANEMOI_WIN;  // sliding-window bits -> 2^(WIN-1) odd powers per lane in LDS
 };
 
+#ifndef ANEMOI_LDS_ENTRIES_9
+#define ANEMOI_LDS_ENTRIES_9 0  // A/B knob: LDS table entries requested by the 9-limb fields (0 = what the window needs)
+#endif
 template <class A, int WIN>
 constexpr size_t lds_table_bytes() {
-  return size_t((1 << (WIN - 1)) - 1) * A::NQ * 16 * kBlock;  // x^3, x^5, ..: x itself stays in VGPRs
+  // x^3, x^5, ..: x itself stays in VGPRs
+  constexpr int need = (1 << (WIN - 1)) - 1;
+  constexpr int entries = (A::NL < 13 && ANEMOI_LDS_ENTRIES_9 > need) ? ANEMOI_LDS_ENTRIES_9 : need;
+  return size_t(entries) * A::NQ * 16 * kBlock;
 }
 
 template <class A, int WIN, int W>
@@ -579,8 +585,9 @@ ANEMOI_KERNEL void k_merkle_climb(const uint4* __restrict__ leaves, const uint64
       st[1].l[i] = right ? cur.l[i] : sib.l[i];
     }
     A::add(sum, cur, sib);
-    // park the feed-forward sum in the accumulator-free part of the round: it is only 1 element
-    permutation<F, A, 2, WIN>(st, pc, tab);
+    // plain window here (USEX = false): with cur, sib and the feed-forward sum live across the permutation the
+    // two extra digits would push this kernel past 168 VGPRs (182 / 138: one wave per SIMD less)
+    permutation<F, A, 2, WIN, false>(st, pc, tab);
     A::add(cur, st[0], st[1]);
     A::add(cur, cur, sum);
     if (A::kLoose) A::settle(cur);
@@ -706,8 +713,8 @@ namespace anemoi {
 struct HostConsts {  // what the context uploads for one (field, width)
   std::vector<uint32_t> ark_c, ark_d;    // lane-private limb layout (F::Lane)
   std::vector<uint32_t> coop_c, coop_d;  // Anemoi-2-1 constants in the cooperative kernels' layout (F::Coop)
-  std::vector<uint8_t> sched, sched5;
-  int steps, first, steps5, first5;
+  std::vector<uint8_t> sched, sched5, sched_plain;
+  int steps, first, steps5, first5, steps_plain, first_plain;
 };
 
 struct FieldOps {
@@ -788,6 +795,11 @@ struct Launch {
     } else {
       hc->sched.assign(F::kW5Sched, F::kW5Sched + 2 * F::kW5Steps);
       hc->steps = F::kW5Steps, hc->first = F::kW5First;
+    }
+    hc->sched_plain = hc->sched, hc->steps_plain = hc->steps, hc->first_plain = hc->first;
+    if (WIN == 3 && F::kXDigits > 0 && ANEMOI_XDIGITS_ON) {  // window 3 + extra digits in VGPRs (anemoi_perm.h)
+      hc->sched.assign(F::kXSched, F::kXSched + 2 * F::kXSteps);
+      hc->steps = F::kXSteps, hc->first = F::kXFirst;
     }
   }
 

@@ -22,6 +22,10 @@
 #include "mont29.h"
 #include "mont32.h"
 
+#ifndef ANEMOI_XDIGITS_ON
+#define ANEMOI_XDIGITS_ON 1  // extra window digits in VGPRs (exp_inv_alpha); 0 = plain window (A/B)
+#endif
+
 namespace anemoi {
 
 // Compile-time loop over state elements: bodies that inline a whole Montgomery product are too big
@@ -72,6 +76,11 @@ struct PermConsts {
   const uint32_t* sched;
   int steps;
   int first;
+  // the plain WIN-bit window schedule, for kernels that cannot spare the registers of the extra digits
+  // (k_merkle_climb): equal to sched / steps / first when the field has no extra digits
+  const uint32_t* sched_plain;
+  int steps_plain;
+  int first_plain;
   // schedule for the wave-cooperative kernels (window F::kCoopWin: their table costs one LDS word per entry)
   const uint32_t* sched5;
   int steps5;
@@ -81,12 +90,50 @@ struct PermConsts {
   const uint32_t* coop_d;
 };
 
+// Source `SRC` of the extra digits' build programme (tools/gen_params.py): 0 = x, 1 = x^2, 2..4 = the LDS table
+// entries x^3, x^5, x^7, 5 = the first extra digit.
+template <class A, int SRC>
+__device__ __forceinline__ void xdigit_src(typename A::Fe& dst, const typename A::Fe& x, const typename A::Fe& x2,
+                                           const typename A::Fe& e0, const LdsTable<A>& tab) {
+  if constexpr (SRC == 0) dst = x;
+  else if constexpr (SRC == 1) dst = x2;
+  else if constexpr (SRC <= 4) tab.load(SRC - 1, dst);
+  else dst = e0;
+}
+
+// x^d for extra digit XI, by its build programme: LOAD a ; [MUL b] ; [SQR k] ; [MUL r]
+template <class F, class A, int XI>
+__device__ __forceinline__ void xdigit_build(typename A::Fe& r, const typename A::Fe& x, const typename A::Fe& x2,
+                                             const typename A::Fe& e0, const LdsTable<A>& tab) {
+  constexpr int OFF = XI == 0 ? 0 : F::kXProgLen[0];
+  static_for<0, F::kXProgLen[XI]>([&](auto k) {
+    constexpr int op = F::kXProgOp[OFF + k], arg = F::kXProgArg[OFF + k];
+    if constexpr (op == 0) {
+      xdigit_src<A, arg>(r, x, x2, e0, tab);
+    } else if constexpr (op == 1) {
+#pragma nounroll
+      for (int q = 0; q < arg; q++) A::esqr(r, r);
+    } else {
+      typename A::Fe s;
+      xdigit_src<A, arg>(s, x, x2, e0, tab);
+      A::emul(r, r, s);
+    }
+  });
+}
+
 // r = x^INV_ALPHA.  WIN-bit sliding window over odd powers; table entry 0 is x itself (registers).
 // In: x < 2^12 p (loose) or canonical.  Out: < 2p (loose) or canonical.
-template <class F, class A, int WIN>
+// With WIN = 3 and F::kXDigits > 0 the table {x, x^3, x^5, x^7} is extended by one or two more powers x^d held
+// in VGPRs (digits and schedule chosen per field by tools/gen_params.py: e.g. 51 = 0b110011 and 59 for BLS12-381,
+// 468 products instead of 478 -- the LDS budget of 3-4 waves per SIMD stops at three entries, the register
+// budget has room for these); a multiplication by such a digit takes its operand straight from the registers.
+template <class F, class A, int WIN, bool USEX = true>
 __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename A::Fe& x, const PermConsts& pc,
                                               const LdsTable<A>& tab) {
   constexpr int E = 1 << (WIN - 1);
+  constexpr bool kX = USEX && WIN == 3 && F::kXDigits > 0 && ANEMOI_XDIGITS_ON;
+  const uint32_t* const sched = kX ? pc.sched : pc.sched_plain;
+  const int steps = kX ? pc.steps : pc.steps_plain, first = kX ? pc.first : pc.first_plain;
   typename A::Fe x2, t, acc;
   A::esqr(x2, x);
   t = x;
@@ -95,13 +142,20 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
     A::emul(t, t, x2);
     tab.store(i, t);
   }
-  if (pc.first == 0) acc = x;
-  else tab.load(pc.first, acc);
+  [[maybe_unused]] typename A::Fe e0, e1;  // the extra digits
+  if constexpr (kX) {
+    xdigit_build<F, A, 0>(e0, x, x2, e0, tab);
+    if constexpr (F::kXDigits > 1) xdigit_build<F, A, 1>(e1, x, x2, e0, tab);
+  }
+  if (first == 0) acc = x;
+  else if (!kX || first < E) tab.load(first, acc);
+  else if (F::kXDigits > 1 && first == E + 1) acc = e1;
+  else acc = e0;
   [[maybe_unused]] typename A::Fe tmp;  // leading-run doubling (Pallas / Vesta), see sliding_window()
   if constexpr (F::kChainTmp) tmp = acc;
 #pragma nounroll
-  for (int s = 0; s < pc.steps; s++) {
-    const uint32_t word = pc.sched[s];
+  for (int s = 0; s < steps; s++) {
+    const uint32_t word = sched[s];
     const int nsq = word & 0xff, idx = word >> 8;
     if constexpr (F::kChainTmp) {
       if (idx == 253) {
@@ -113,6 +167,10 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
     for (int q = 0; q < nsq; q++) A::esqr(acc, acc);
     if (F::kChainTmp && idx == 254) {
       A::emul(acc, acc, tmp);
+    } else if (kX && idx == E) {
+      A::emul(acc, acc, e0);
+    } else if (kX && F::kXDigits > 1 && idx == E + 1) {
+      A::emul(acc, acc, e1);
     } else if (idx != 255) {
       if (idx == 0) t = x;
       else tab.load(idx, t);
@@ -134,14 +192,14 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
 //     u < 2 ; x' < 6 ; squarings of x', y' have A B = 36 <= H ; t < 2 ; y' < 6 ; x'' < 6 + 2 + 1 = 9
 //   BLS12-381 on 30-bit limbs (H = 630, g = 2 by limb-wise doubling, subtraction pads with 8 p):
 //     u < 4 ; x' < 10 ; A B = 100 <= H ; t < 2 ; y' < 10 ; x'' < 10 + 4 + 1 = 15
-template <class F, class A, int WIN>
+template <class F, class A, int WIN, bool USEX = true>
 __device__ __forceinline__ void flystel(typename A::Fe& x, typename A::Fe& y, const PermConsts& pc,
                                         const LdsTable<A>& tab) {
   typename A::Fe t, u;
   A::sqr(t, y);
   A::mul_g(u, t);
   A::sub(x, x, u);
-  exp_inv_alpha<F, A, WIN>(t, x, pc, tab);
+  exp_inv_alpha<F, A, WIN, USEX>(t, x, pc, tab);
   A::sub(y, y, t);
   A::sqr(t, y);
   A::mul_g(u, t);
@@ -191,16 +249,16 @@ __device__ __forceinline__ void add_global(typename A::Fe& r, const uint32_t* __
   A::add_k(r, r, c);
 }
 
-template <class F, class A, int W, int WIN>
+template <class F, class A, int W, int WIN, bool USEX = true>
 __device__ __forceinline__ void sbox_layer(typename A::Fe (&st)[W], const PermConsts& pc, const LdsTable<A>& tab) {
   // columns spelled out: the S-box body is too large to unroll by pragma, and a rolled loop would
   // index the register-resident state dynamically (scratch)
-  flystel<F, A, WIN>(st[0], st[W / 2], pc, tab);
-  if (W == 4) flystel<F, A, WIN>(st[1], st[3], pc, tab);
+  flystel<F, A, WIN, USEX>(st[0], st[W / 2], pc, tab);
+  if (W == 4) flystel<F, A, WIN, USEX>(st[1], st[3], pc, tab);
 }
 
 // Full permutation (src/traits.rs:370-378)
-template <class F, class A, int W, int WIN>
+template <class F, class A, int W, int WIN, bool USEX = true>
 __device__ __forceinline__ void permutation(typename A::Fe (&st)[W], const PermConsts& pc, const LdsTable<A>& tab) {
   constexpr int C = W / 2;
   constexpr int R = W == 2 ? F::kRounds21 : F::kRounds43;
@@ -211,7 +269,7 @@ __device__ __forceinline__ void permutation(typename A::Fe (&st)[W], const PermC
       add_global<A>(st[C + i], pc.ark_d + (r * C + i) * A::NL);
     });
     mds_layer<F, A, W>(st);
-    sbox_layer<F, A, W, WIN>(st, pc, tab);
+    sbox_layer<F, A, W, WIN, USEX>(st, pc, tab);
   }
   mds_layer<F, A, W>(st);
 }

@@ -185,11 +185,11 @@ inline int get_consts(int field, int width, PermConsts* out) {
       for (size_t i = 0; i < w.size(); i++) w[i] = uint32_t(pairs[2 * i]) | (uint32_t(pairs[2 * i + 1]) << 8);
       return w;
     };
-    const std::vector<uint32_t> s3 = words(hc.sched), s5 = words(hc.sched5);
-    const std::vector<uint32_t>* parts[6] = {&hc.ark_c, &hc.ark_d, &s3, &s5, &hc.coop_c, &hc.coop_d};
-    size_t off[7] = {0};
+    const std::vector<uint32_t> s3 = words(hc.sched), s5 = words(hc.sched5), sp = words(hc.sched_plain);
+    const std::vector<uint32_t>* parts[7] = {&hc.ark_c, &hc.ark_d, &s3, &s5, &hc.coop_c, &hc.coop_d, &sp};
+    size_t off[8] = {0};
     std::vector<uint32_t> host;
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 7; i++) {
       off[i + 1] = off[i] + parts[i]->size();
       host.insert(host.end(), parts[i]->begin(), parts[i]->end());
     }
@@ -211,6 +211,9 @@ inline int get_consts(int field, int width, PermConsts* out) {
     pc.first5 = hc.first5;
     pc.coop_c = blob + off[4];
     pc.coop_d = blob + off[5];
+    pc.sched_plain = blob + off[6];
+    pc.steps_plain = hc.steps_plain;
+    pc.first_plain = hc.first_plain;
     c.pc[field][wi] = pc;
     c.blob[field][wi] = blob;
     c.ready[field][wi] = true;

@@ -277,6 +277,7 @@ def main():
         value = total_items / elapsed
         achieved = BYTES_PER_ITEM * n / (kernel_ms * 1e-3) / 1e9
         mad_per_item = buildinfo.bls12_381_mad_per_compression()
+        lay, (sq_r, mu_r) = buildinfo.bls12_381_limb_layout(), buildinfo.bls12_381_products_per_round()
         lane_mad_per_s = mad_per_item * n / (kernel_ms * 1e-3)
         clock = prof_clock or NOMINAL_GHZ
         out = {
@@ -310,9 +311,10 @@ def main():
                     "valu_instr_per_item": valu_per_item,
                     "valu_util": (valu_per_item * n / (kernel_ms * 1e-3) / (SIMDS * LANES_PER_CLK * clock * 1e9))
                     if valu_per_item else None,
-                    "note": "v_mad_u64_u32 lane-operations per second (count per compression from the generated assembly: "
-                            "21 rounds x (381 squarings x 260 + 101 multiplications x 338) + 5 x 338) against 1024 SIMDs x "
-                            "16 lanes per clock; the path is VALU-issue bound, see DESIGN.md"},
+                    "note": "v_mad_u64_u32 lane-operations per second (count per compression from the generated assembly and "
+                            "exponent schedule: 21 rounds x (%d squarings x %d + %d multiplications x %d) + 5 x %d) against "
+                            "1024 SIMDs x 16 lanes per clock; the path is VALU-bound, see DESIGN.md"
+                            % (sq_r, lay["sqr_mad"], mu_r, lay["mul_mad"], lay["mul_mad"])},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth)

@@ -20,6 +20,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELD_IDS = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
 MAXL = 6
 MAXR21, MAXR43 = 21, 14
+# extra window digits held in VGPRs per field (0 = plain 3-bit window); see extra_digit_schedule()
+XDIGITS = {"bls12_381": 2, "bls12_377": 2, "bn_254": 2, "ed_on_bls12_377": 2, "jubjub": 2}
+if __import__("os").environ.get("ANEMOI_XDIGITS") is not None:
+    XDIGITS = {k: int(__import__("os").environ["ANEMOI_XDIGITS"]) for k in XDIGITS}
 
 
 def limbs64(v, n):
@@ -90,6 +94,136 @@ def sliding_window(e, k):
     if pend:
         steps.append((pend, 255))
     return first, steps
+
+
+# ---- window table with extra digits -----------------------------------------------------------------------
+# The 3-bit window's table {x, x^3, x^5, x^7} is what fits in LDS next to 3-4 waves per SIMD; the spare VGPRs hold
+# one or two MORE powers x^d.  Which d?  Not 9 and 11: 1/alpha mod (p - 1) of these primes has runs of repeated
+# nibbles (..2233332277666662e65999999995555 for BLS12-381), and digits like 51 = 0b110011 or 17 = 0b10001
+# swallow two windows at once.  For every candidate d (odd, < 2^12) an optimal left-to-right recoding over the digit
+# set {1, 3, 5, 7, d1[, d2]} (dynamic programme over the bit positions, windows up to 12 bits) is priced together
+# with the cheapest way to build x^d from what is at hand while the table is being built (x, x^2, x^3, x^5, x^7, the
+# first extra): LOAD a ; [MUL b] ; SQR k ; [MUL r].
+XBASE = (1, 3, 5, 7)
+XMAXW = 12
+XSRC = {1: 0, 2: 1, 3: 2, 5: 3, 7: 4}   # source ids of the build programme: x, x^2, table entries 1..3; 5 = first extra
+
+
+def digit_dp(e, digits, maxw=XMAXW):
+    """optimal recoding of e over the odd digit set: returns (multiplications, first digit, [(squarings, digit|None)])"""
+    bits = bin(e)[2:]
+    n = len(bits)
+    INF = 10 ** 9
+    best, choice = [INF] * (n + 1), [None] * (n + 1)
+    best[n] = 0
+    dset = set(digits)
+    for i in range(n - 1, -1, -1):
+        if bits[i] == "0":
+            best[i], choice[i] = best[i + 1], (1, None)
+            continue
+        v = 0
+        for w in range(1, maxw + 1):
+            j = i + w
+            if j > n:
+                break
+            v = (v << 1) | (bits[j - 1] == "1")
+            if bits[j - 1] == "1" and v in dset and best[j] + 1 < best[i]:
+                best[i], choice[i] = best[j] + 1, (w, v)
+    w0, first = choice[0]
+    steps, i, pend = [], w0, 0
+    while i < n:
+        w, v = choice[i]
+        if v is None:
+            pend += 1
+        else:
+            steps.append((pend + w, v))
+            pend = 0
+        i += w
+    if pend:
+        steps.append((pend, None))
+    return best[0] - 1, first, steps
+
+
+def digit_chain(d, avail):
+    """cheapest programme (list of ops) that leaves x^d in the build register: ("load", a) [("mul", b)] ("sqr", k)
+    [("mul", r)] with a, b, r among the exponents in `avail`"""
+    best = None
+    cands = []
+    for a in avail:
+        cands.append((a, [("load", a)]))
+    for a in avail:
+        for b in avail:
+            if a <= b:
+                cands.append((a + b, [("load", a), ("mul", b)]))
+    for h, prog in cands:
+        for k in range(0, XMAXW + 1):
+            r = d - (h << k)
+            if r < 0:
+                break
+            if r != 0 and r not in avail:
+                continue
+            ops = prog + ([("sqr", k)] if k else []) + ([("mul", r)] if r else [])
+            cost = sum(o[1] if o[0] == "sqr" else (1 if o[0] == "mul" else 0) for o in ops)
+            if cost and (best is None or cost < best[0]):
+                best = (cost, ops)
+    return best
+
+
+def extra_digit_schedule(e, n_extra):
+    """-> (extras [(digit, ops)], first digit, steps, products incl. the whole table build)"""
+    avail0 = [1, 2, 3, 5, 7]
+    base_cost, first, steps = digit_dp(e, XBASE)
+    best = (base_cost + 4, [], first, steps)
+    if n_extra == 0:
+        return best[1], best[2], best[3], best[0]
+    singles = []
+    for d in range(9, 1 << XMAXW, 2):
+        ch = digit_chain(d, avail0)
+        if ch:
+            m, f, st = digit_dp(e, XBASE + (d,))
+            singles.append((m + 4 + ch[0], d, ch[1], f, st))
+    singles.sort(key=lambda t: t[0])
+    if singles[0][0] < best[0]:
+        c, d, ops, f, st = singles[0]
+        best = (c, [(d, ops)], f, st)
+    if n_extra >= 2:
+        for c1, d1, ops1, _, _ in singles[:10]:
+            cost1 = c1 - digit_dp(e, XBASE + (d1,))[0] - 4
+            for d2 in range(9, 1 << XMAXW, 2):
+                if d2 == d1:
+                    continue
+                ch = digit_chain(d2, avail0 + [d1])
+                if not ch:
+                    continue
+                m, f, st = digit_dp(e, XBASE + (d1, d2))
+                c = m + 4 + cost1 + ch[0]
+                if c < best[0]:
+                    best = (c, [(d1, ops1), (d2, ch[1])], f, st)
+    return best[1], best[2], best[3], best[0]
+
+
+def check_extra_schedule(e, extras, first, steps, p):
+    x = 0x1234567 % p
+    val = {1: x, 2: x * x % p}
+    for d in (3, 5, 7):
+        val[d] = val[d - 2] * val[2] % p
+    for d, ops in extras:
+        r = None
+        for op, arg in ops:
+            if op == "load":
+                r = val[arg]
+            elif op == "sqr":
+                r = pow(r, 1 << arg, p)
+            else:
+                r = r * val[arg] % p
+        assert r == pow(x, d, p), (d, ops)
+        val[d] = r
+    acc = val[first]
+    for s, d in steps:
+        acc = pow(acc, 1 << s, p)
+        if d is not None:
+            acc = acc * val[d] % p
+    assert acc == pow(x, e, p)
 
 
 def check_schedule(e, k, first, steps, p):
@@ -252,6 +386,36 @@ def main():
         h.append("  static constexpr int kCoopWin = %d;" % min(cost, key=cost.get))
         h.append("  static constexpr bool kChainTmp = %s;  // the schedules use the tmp register (ops 253 / 254)" % (
             "true" if uses_tmp else "false"))
+        # window-3 table + extra digits held in VGPRs (anemoi_perm.h exp_inv_alpha); not for the fields whose exponent
+        # starts with a long run that the tmp doubling already handles (Pallas / Vesta)
+        n_extra = 0 if uses_tmp else XDIGITS.get(name, 0)
+        extras, xfirst, xsteps, xcost = extra_digit_schedule(e, n_extra)
+        check_extra_schedule(e, extras, xfirst, xsteps, p)
+        digits = list(XBASE) + [d for d, _ in extras]
+        src_id = dict(XSRC)
+        if extras:
+            src_id[extras[0][0]] = 5
+        ops_flat, args_flat, lens = [], [], []
+        for d, ops in extras:
+            lens.append(len(ops))
+            for op, arg in ops:
+                ops_flat.append({"load": 0, "sqr": 1, "mul": 2}[op])
+                args_flat.append(arg if op == "sqr" else src_id[arg])
+        flat = []
+        for s_, d_ in xsteps:
+            assert s_ < 256
+            flat += [s_, 255 if d_ is None else digits.index(d_)]
+        nsq = sum(s_ for s_, _ in xsteps) + sum(a for o, a in zip(ops_flat, args_flat) if o == 1)
+        h.append("  // window 3 + %d extra digit(s) %s: %d products in all (table build included) against %d for the plain 3-bit window"
+                 % (len(extras), [d for d, _ in extras], xcost + sum(s_ for s_, _ in xsteps), cost[3][0]))
+        h.append("  static constexpr int kXDigits = %d, kXFirst = %d, kXSteps = %d;" % (len(extras), digits.index(xfirst), len(xsteps)))
+        h.append("  static constexpr int kXDigit[%d] = {%s};" % (max(len(extras), 1), ",".join(str(d) for d, _ in extras) or "0"))
+        h.append("  static constexpr int kXProgLen[%d] = {%s};  // build programme of each extra: ops 0 = LOAD src, 1 = SQR k, 2 = MUL src"
+                 % (max(len(lens), 1), ",".join(map(str, lens)) or "0"))
+        h.append("  static constexpr int kXProgOp[%d] = {%s};" % (max(len(ops_flat), 1), ",".join(map(str, ops_flat)) or "0"))
+        h.append("  static constexpr int kXProgArg[%d] = {%s};  // src: 0 = x, 1 = x^2, 2..4 = x^3, x^5, x^7, 5 = first extra"
+                 % (max(len(args_flat), 1), ",".join(map(str, args_flat)) or "0"))
+        h.append("  static constexpr uint8_t kXSched[%d] = {%s};" % (max(len(flat), 1), ",".join(map(str, flat)) or "0"))
         h.append("};")
 
     o.append("};\n#endif")
