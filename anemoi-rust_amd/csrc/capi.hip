@@ -333,8 +333,17 @@ int sponge_host(int field, int width, int bytes, const void* src, size_t per_msg
       const char* in = (const char*)src + first * per_msg_bytes;
       char* o = (char*)out + first * eb;
       const size_t quantum = quantum_of(field, anemoi::kKindSponge, width, dev);
-      if (count < 2 * quantum && want_segments(count, per_msg_bytes, unit))
-        return sponge_segments(ln, field, width, bytes, in, per_msg, count, o);
+      // Few messages (cannot be cut by message), or long ones (a message chunk of one quantum would be hundreds of
+      // MB of staging): feed blocks of at most one quantum of messages segment by segment.
+      const size_t blk = count < 2 * quantum ? count : quantum;
+      if (want_segments(blk, per_msg_bytes, unit) && (count < 2 * quantum || quantum * per_msg_bytes > (size_t(256) << 20))) {
+        for (size_t b = 0; b < count; b += blk) {
+          const size_t m = count - b < blk ? count - b : blk;
+          int r = sponge_segments(ln, field, width, bytes, in + b * per_msg_bytes, per_msg, m, o + b * eb);
+          if (r) return r;
+        }
+        return ANEMOI_OK;
+      }
       return rt::pipeline(ln, count, in, per_msg_bytes, o, eb, quantum, [&](void* i, void* d, size_t cnt, hipStream_t s) {
         return bytes ? anemoi_hash_bytes_dev(field, width, i, per_msg, cnt, d, s)
                      : anemoi_hash_field_dev(field, width, i, per_msg, cnt, d, s);

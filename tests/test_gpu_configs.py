@@ -295,6 +295,22 @@ def test_sponge_fed_segment_by_segment(A, oracle, synth):
             os.environ["ANEMOI_SPONGE_SEGMENT_BYTES"] = prev
 
 
+def test_many_long_messages_go_block_by_block_through_the_segment_path(A, oracle, synth):
+    """More than two waves of workgroups of messages that are long enough for a one-quantum message chunk to exceed
+    256 MB of staging: the host path feeds blocks of one quantum of messages, each segment by segment.  550 MB of
+    input; every 997th digest against the oracle, and a shuffled copy of the batch must give the shuffled digests."""
+    fid = FIELD_IDS.index("bn_254")
+    n, ln = 2 * 131072 + 77, 2100
+    msgs = synth.messages(0x5E6, 0, n, 2104)[:, :ln].copy()
+    inst = A.Anemoi("bn_254", 4)
+    got = inst.hash_batch(msgs)
+    idx = np.arange(0, n, 997)
+    assert (got[idx] == oracle.hash_bytes_batch(fid, 4, msgs[idx], threads=8)).all()
+    assert (got[-3:] == oracle.hash_bytes_batch(fid, 4, msgs[-3:], threads=2)).all()
+    perm = np.random.default_rng(3).permutation(n)[:50000]
+    assert (inst.hash_batch(msgs[perm]) == got[perm]).all()
+
+
 def test_ragged_batch_of_messages_of_different_lengths(A, oracle):
     """anemoi_hash_bytes_ragged_batch: one launch over messages of different lengths (empty, 1 byte, around the
     chunk and rate-block boundaries, long), both widths, 4- and 6-limb fields, also sharded; every digest equals
