@@ -192,6 +192,7 @@ int subtree_host(Lane& ln, TreeShape ts, const char* leaves, unsigned depth, cha
   const int W = ts.width(), K = ts.arity();
   if (depth == 0) {
     memcpy(root_host, leaves, eb);
+    if (tree_host && tree_host + part * eb != leaves) memcpy(tree_host + part * eb, leaves, eb);
     return ANEMOI_OK;
   }
   PermConsts pc;
@@ -235,17 +236,26 @@ int subtree_host(Lane& ln, TreeShape ts, const char* leaves, unsigned depth, cha
   if ((rc = mark(1))) return rc;
   const char* src = lvl;
   size_t n = n1;
+  // level 0 of the retained tree = this part's leaves: a host-to-host copy, done once level 2 is queued
+  const size_t nleaf = size_t(K) * n1;
+  char* lvl0 = tree_host ? tree_host + part * nleaf * eb : nullptr;
+  bool leaves_copied = !tree_host || lvl0 == leaves;
   for (unsigned l = 2; l <= depth; l++) {
     char* dst = (char*)src + n * eb;
     const size_t below = n;
     n >>= ts.alog;
     HIP_TRY(ops->jive(W, K, src, dst, n, pc, ln.s_k));
     if ((rc = mark(l))) return rc;
+    if (!leaves_copied) {
+      memcpy(lvl0, leaves, nleaf * eb);
+      leaves_copied = true;
+    }
     // the copy of level l-1 is issued AFTER level l's kernel is queued: a D2H into pageable memory
     // blocks the host until the data is there, and the GPU should not wait for the host meanwhile
     if ((rc = level_out(l - 1, src, below))) return rc;
     src = dst;
   }
+  if (!leaves_copied) memcpy(lvl0, leaves, nleaf * eb);  // (depth 1: no level 2 to hide it under)
   if ((rc = level_out(depth, src, 1))) return rc;
   HIP_TRY(hipMemcpyAsync(root_host, src, eb, hipMemcpyDeviceToHost, ln.s_k));
   HIP_TRY(hipStreamSynchronize(ln.s_k));
@@ -380,8 +390,7 @@ int merkle_host(TreeShape ts, const uint64_t* leaves, unsigned depth, uint64_t* 
     g_last_error = "device ordinal out of range";
     return ANEMOI_ERR_DEVICE;
   }
-  const size_t nleaf = size_t(1) << (ts.alog * depth);
-  if (tree && (const void*)tree != (const void*)leaves) memcpy(tree, leaves, nleaf * eb);  // level 0
+  // (level 0 of a retained tree -- the leaves themselves -- is copied by subtree_host, under the GPU's work)
   const unsigned sub_lv = device == ANEMOI_ALL_DEVICES ? host::subtree_levels(depth, ts.alog, size_t(rt::shard_parts(ndev))) : 0;
   std::vector<uint64_t> root_buf(eb / 8);
   if (sub_lv == 0) {

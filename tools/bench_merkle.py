@@ -62,3 +62,13 @@ for parts in (1, 2, 4, 8, 16, 32):
         t0 = time.perf_counter(); r = inst.merkle_root(leaves, depth); ts.append(time.perf_counter() - t0)
     assert (r == root_dev).all()
     print("  host leaves, %2d concurrent subtrees: %.2f ms" % (parts, sorted(ts)[1] * 1e3))
+
+# the retained-level builder from host leaves (every level copied back to the caller's tree array)
+one = A.Anemoi(field, 2, device=0)
+os.environ.pop("ANEMOI_VIRTUAL_DEVICES", None)
+one.merkle_tree(leaves, depth)
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); lv = one.merkle_tree(leaves, depth); ts.append(time.perf_counter() - t0)
+assert (lv[-1][0] == root_dev).all()
+print("  host leaves -> retained tree (all %d levels copied out, %d MiB): %.2f ms" % (depth + 1, ((2 << depth) - 1) * L * 8 >> 20, sorted(ts)[1] * 1e3))
