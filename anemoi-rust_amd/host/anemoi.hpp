@@ -145,6 +145,38 @@ struct Instance {
     check(anemoi_hash_bytes_batch(FIELD, WIDTH, msgs, msg_len, n, n ? out[0].elements[0].limbs.data() : nullptr, device));
     return out;
   }
+  // Sponge::hash of each of `msgs` (any lengths) in one launch: item i == hash(msgs[i])
+  static std::vector<D> hash_ragged(const std::vector<std::vector<uint8_t>>& msgs, int device = 0) {
+    std::vector<uint64_t> off(msgs.size() + 1, 0);
+    for (size_t i = 0; i < msgs.size(); i++) off[i + 1] = off[i] + msgs[i].size();
+    std::vector<uint8_t> blob;
+    blob.reserve(off.back());
+    for (const auto& m : msgs) blob.insert(blob.end(), m.begin(), m.end());
+    std::vector<D> out(msgs.size());
+    check(anemoi_hash_bytes_ragged_batch(FIELD, WIDTH, blob.empty() ? nullptr : blob.data(), off.data(), msgs.size(),
+                                         msgs.empty() ? nullptr : out[0].elements[0].limbs.data(), device));
+    return out;
+  }
+  // n pairs of digests -> n digests, item i == merge(pairs[i]) (the 4-3 form keeps the reference's behaviour, see merge)
+  static std::vector<D> merge_batch(const std::vector<std::array<D, 2>>& pairs, int device = 0) {
+    std::vector<D> out(pairs.size());
+    if (pairs.empty()) return out;
+    if (WIDTH == 2) {
+      static_assert(sizeof(std::array<D, 2>) == 2 * sizeof(uint64_t) * LIMBS, "pairs must be contiguous elements");
+      check(anemoi_merge_batch(FIELD, pairs[0][0].elements[0].limbs.data(), out[0].elements[0].limbs.data(), pairs.size(),
+                               device));
+    } else {
+      std::vector<F> st(pairs.size() * 4);
+      for (size_t i = 0; i < pairs.size(); i++) st[4 * i] = st[4 * i + 1] = pairs[i][0].elements[0];
+      check(anemoi_permutation_batch(FIELD, WIDTH, st[0].limbs.data(), pairs.size(), device));
+      for (size_t i = 0; i < pairs.size(); i++) out[i].elements[0] = st[4 * i];
+    }
+    return out;
+  }
+  // optional warm-up / release of the library's per-device state (constant tables, lanes)
+  static void init(int device = ANEMOI_ALL_DEVICES) { check(anemoi_init(device, FIELD, WIDTH)); }
+  static void release(int device = ANEMOI_ALL_DEVICES) { check(anemoi_release(device)); }
+
   static D merkle_root(const std::vector<D>& leaves, unsigned depth, int device = 0) {
     static_assert(WIDTH == 2, "the Merkle driver uses the 2-1 instance's merge");
     if (leaves.size() != (size_t(1) << depth)) throw std::invalid_argument("merkle_root: need 2^depth leaves");

@@ -131,6 +131,27 @@ int main(int argc, char** argv) {
     CASE(4, 4, AnemoiJubjub_4_3) CASE(5, 2, AnemoiPallas_2_1) CASE(5, 4, AnemoiPallas_4_3)
     CASE(6, 2, AnemoiVesta_2_1) CASE(6, 4, AnemoiVesta_4_3)
   }
+  // the batched forms reduce to the single-item functions: ragged hash, merge_batch (2-1 and the 4-3 form)
+  {
+    using I = AnemoiBn254_4_3;
+    I::init(0);
+    std::vector<std::vector<uint8_t>> msgs = {{}, {1}, std::vector<uint8_t>(93, 7), std::vector<uint8_t>(200, 9)};
+    for (size_t i = 0; i < msgs[3].size(); i++) msgs[3][i] = uint8_t(i * 31 + 5);
+    auto got = I::hash_ragged(msgs);
+    for (size_t i = 0; i < msgs.size(); i++) EXPECT(got[i] == I::hash(msgs[i]), "hash_ragged item");
+    using J = AnemoiJubjub_2_1;
+    std::vector<std::array<J::D, 2>> pairs(5);
+    for (size_t i = 0; i < pairs.size(); i++) {
+      pairs[i][0] = J::hash(std::vector<uint8_t>(10 + i, uint8_t(i)));
+      pairs[i][1] = J::hash(std::vector<uint8_t>(40 + i, uint8_t(3 * i)));
+    }
+    auto mb = J::merge_batch(pairs);
+    for (size_t i = 0; i < pairs.size(); i++) EXPECT(mb[i] == J::merge(pairs[i]), "merge_batch 2-1 item");
+    std::vector<std::array<I::D, 2>> pairs4(3);
+    for (size_t i = 0; i < pairs4.size(); i++) pairs4[i] = {got[i], got[i + 1]};
+    auto mb4 = I::merge_batch(pairs4);
+    for (size_t i = 0; i < pairs4.size(); i++) EXPECT(mb4[i] == I::merge(pairs4[i]), "merge_batch 4-3 item");
+  }
   // digest_elements / to_bytes (digest.rs:66-88): the zero digest serialises to zero bytes
   AnemoiBls12_381_2_1::D zero;
   for (auto b : zero.to_bytes()) EXPECT(b == 0, "to_bytes(zero)");
