@@ -90,8 +90,9 @@ int anemoi_num_rounds(int field, int width); /* NUM_HASH_ROUNDS, src/<f>/anemoi_
  * Optional.  anemoi_init uploads the constant tables of (field, width) to `device` (or to every device
  * with ANEMOI_ALL_DEVICES) and creates one lane, so that later calls -- `_dev` calls in particular --
  * neither allocate nor synchronise.  anemoi_release frees everything the library holds on `device`
- * (constant tables, idle lanes with their streams and buffers); ANEMOI_ERR_ARG while other calls are in
- * flight there.  The library can be used again afterwards (it re-initialises lazily). */
+ * (constant tables, idle lanes with their streams and buffers); ANEMOI_ERR_ARG while host-pointer calls are in
+ * flight there.  `_dev` work the caller has enqueued on its own streams is the caller's to wait for first: its
+ * kernels read the constant tables.  The library can be used again afterwards (it re-initialises lazily). */
 int anemoi_init(int device, int field, int width);
 int anemoi_release(int device);
 
