@@ -39,8 +39,9 @@
  *
  * ENVIRONMENT (diagnostics): ANEMOI_VIRTUAL_DEVICES=N makes ANEMOI_ALL_DEVICES shard into N ranges /
  * subtrees mapped round-robin onto the physical GPUs (exercises the multi-GPU code on one GPU);
- * ANEMOI_HOST_STAGING=direct|pinned selects how host buffers are copied; ANEMOI_COOP_MAX overrides the
- * batch size below which Jive 2-to-1 takes the wave-cooperative latency kernel.
+ * ANEMOI_HOST_STAGING=direct|pinned selects how host buffers are copied; ANEMOI_SPONGE_SEGMENT_BYTES forces the
+ * segment size of the sponge's host path (long messages are absorbed segment by segment, copies under kernels);
+ * ANEMOI_COOP_MAX overrides the batch size below which Jive 2-to-1 takes the wave-cooperative latency kernel.
  */
 #ifndef ANEMOI_MI355X_H
 #define ANEMOI_MI355X_H
