@@ -381,6 +381,24 @@ inline int staging_mode() {
   return 1;
 }
 
+// Is [p, p + bytes) host memory that HIP already knows as pinned (hipHostMalloc / hipHostRegister)?  Then the
+// DMA engines can read / write it directly and staging would only add a memcpy.
+inline bool is_pinned_host(const void* p, size_t bytes) {
+  if (!p || !bytes) return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // ordinary pageable memory: "invalid value", not an error of ours
+    return false;
+  }
+  if (a.type != hipMemoryTypeHost) return false;
+  hipPointerAttribute_t b;
+  if (hipPointerGetAttributes(&b, (const char*)p + bytes - 1) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return b.type == hipMemoryTypeHost;
+}
+
 // The chunked pipeline on one device: items [0, n) of `in` -> `out` (host pointers; out == in means in
 // place).  launch(d_in, d_out, count, stream) enqueues the kernel for one chunk.
 // With d_dst != nullptr the outputs stay on the device (chunk c's at d_dst + first * opi) and `out` is unused:
@@ -392,6 +410,8 @@ int pipeline(Lane& ln, size_t n, const char* in, size_t ipi, char* out, size_t o
   const host::ChunkPlan cp = host::plan_chunks(n, quantum, ipi, kChunkTargetBytes);
   if (cp.chunks == 0) return ANEMOI_OK;
   bool staged = staging_mode() == 1;
+  // the caller's buffers are pinned already (e.g. a pinned tensor, hipHostRegister'ed memory): copy straight
+  if (staged && is_pinned_host(in, n * ipi) && (d_dst || is_pinned_host(out, n * opi))) staged = false;
   // Pinned staging is an optimisation: when the host cannot pin that much (locked-memory limits), fall back to
   // copying straight from the caller's memory instead of failing the call.
   auto pin = [&](Slot& sl, size_t in_bytes, size_t out_bytes) {
