@@ -326,7 +326,7 @@ inline int shard_parts(int ndev) {
   const char* e = getenv("ANEMOI_VIRTUAL_DEVICES");
   if (e && *e) {
     const long v = strtol(e, nullptr, 10);
-    if (v >= 1 && v <= 1024) return int(v);
+    if (v >= 1 && v <= kMaxDevices) return int(v);
   }
   return ndev;
 }
