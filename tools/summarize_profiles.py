@@ -119,6 +119,11 @@ def main():
     out = {
         "csrc_sha256": buildinfo.csrc_sha256(),   # bench.py reports `traffic` only for the sources this describes
         "products_per_round": {"squarings": sq_per_round, "multiplications": mul_per_round},
+        # the dispatch record of the headline kernel as rocprofv3 reports it (its VGPR_Count is in allocation units of 2
+        # registers on gfx950 and LDS_Block_Size does not include dynamic LDS: the kernel has 167 VGPRs, 12 KiB of LDS)
+        "kernel_dispatch": {k: tr[0][k] for k in ("Kernel_Name", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
+                                                    "Accum_VGPR_Count", "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X")
+                            if k in tr[0]},
         "counters_avg_per_launch": c, "derived": derived, "limb_layout": mc,
         "rocprofv3_stats_avg_ms": sum(dur) / len(dur), "rocprofv3_stats_calls": len(dur),
         "note": "rocprofv3 --pmc passes (separate runs for FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set) of `python3 "
