@@ -38,10 +38,12 @@ fn check(rc: core::ffi::c_int) {
     assert!(rc == ffi::ANEMOI_OK, "anemoi_mi355x error {}", rc);
 }
 
+// (the module is taken as `ident :: ident :: ...` and not as a `path` fragment: a captured path cannot be extended
+// with further segments in a `use`)
 macro_rules! impl_mi355x {
-    ($module:path, $inst:ident, $field_id:expr, $limbs:expr, $width:expr) => {
+    ($($module:ident)::+, $inst:ident, $field_id:expr, $limbs:expr, $width:expr) => {
         const _: () = {
-            use $module::{digest::AnemoiDigest, Felt, $inst, DIGEST_SIZE, STATE_WIDTH};
+            use $($module)::+::{digest::AnemoiDigest, Felt, $inst, DIGEST_SIZE, STATE_WIDTH};
 
             // `&[Felt]` is handed to C as `*const u64`: arkworks `Fp<MontBackend<_, L>, L>` is
             // `Fp(BigInt<L>([u64; L]), PhantomData)` -- L Montgomery limbs -- but neither type is
