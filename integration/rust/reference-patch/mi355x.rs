@@ -38,12 +38,14 @@ fn check(rc: core::ffi::c_int) {
     assert!(rc == ffi::ANEMOI_OK, "anemoi_mi355x error {}", rc);
 }
 
-// (the module is taken as `ident :: ident :: ...` and not as a `path` fragment: a captured path cannot be extended
-// with further segments in a `use`)
+// $field / $shape are the reference's module names (src/lib.rs:27-64, src/<field>/mod.rs:8-12): `Felt` is the field
+// module's public alias (src/<field>/mod.rs:1), the digest type and the sizes are the instance module's public items
+// (src/<field>/anemoi_X_Y/mod.rs:13-31).
 macro_rules! impl_mi355x {
-    ($($module:ident)::+, $inst:ident, $field_id:expr, $limbs:expr, $width:expr) => {
+    ($field:ident, $shape:ident, $inst:ident, $field_id:expr, $limbs:expr, $width:expr) => {
         const _: () = {
-            use $($module)::+::{digest::AnemoiDigest, Felt, $inst, DIGEST_SIZE, STATE_WIDTH};
+            use crate::$field::$shape::{AnemoiDigest, $inst, DIGEST_SIZE, STATE_WIDTH};
+            use crate::$field::Felt;
 
             // `&[Felt]` is handed to C as `*const u64`: arkworks `Fp<MontBackend<_, L>, L>` is
             // `Fp(BigInt<L>([u64; L]), PhantomData)` -- L Montgomery limbs -- but neither type is
@@ -181,30 +183,30 @@ macro_rules! impl_mi355x {
 
 // field ids = include/anemoi_mi355x.h; limbs = u64 limbs of `Felt`; one line per instance of src/lib.rs:27-64
 #[cfg(feature = "bls12_381")]
-impl_mi355x!(crate::bls12_381::anemoi_2_1, AnemoiBls12_381_2_1, ffi::ANEMOI_BLS12_381, 6, 2);
+impl_mi355x!(bls12_381, anemoi_2_1, AnemoiBls12_381_2_1, ffi::ANEMOI_BLS12_381, 6, 2);
 #[cfg(feature = "bls12_381")]
-impl_mi355x!(crate::bls12_381::anemoi_4_3, AnemoiBls12_381_4_3, ffi::ANEMOI_BLS12_381, 6, 4);
+impl_mi355x!(bls12_381, anemoi_4_3, AnemoiBls12_381_4_3, ffi::ANEMOI_BLS12_381, 6, 4);
 #[cfg(feature = "bls12_377")]
-impl_mi355x!(crate::bls12_377::anemoi_2_1, AnemoiBls12_377_2_1, ffi::ANEMOI_BLS12_377, 6, 2);
+impl_mi355x!(bls12_377, anemoi_2_1, AnemoiBls12_377_2_1, ffi::ANEMOI_BLS12_377, 6, 2);
 #[cfg(feature = "bls12_377")]
-impl_mi355x!(crate::bls12_377::anemoi_4_3, AnemoiBls12_377_4_3, ffi::ANEMOI_BLS12_377, 6, 4);
+impl_mi355x!(bls12_377, anemoi_4_3, AnemoiBls12_377_4_3, ffi::ANEMOI_BLS12_377, 6, 4);
 #[cfg(feature = "bn_254")]
-impl_mi355x!(crate::bn_254::anemoi_2_1, AnemoiBn254_2_1, ffi::ANEMOI_BN_254, 4, 2);
+impl_mi355x!(bn_254, anemoi_2_1, AnemoiBn254_2_1, ffi::ANEMOI_BN_254, 4, 2);
 #[cfg(feature = "bn_254")]
-impl_mi355x!(crate::bn_254::anemoi_4_3, AnemoiBn254_4_3, ffi::ANEMOI_BN_254, 4, 4);
+impl_mi355x!(bn_254, anemoi_4_3, AnemoiBn254_4_3, ffi::ANEMOI_BN_254, 4, 4);
 #[cfg(feature = "ed_on_bls12_377")]
-impl_mi355x!(crate::ed_on_bls12_377::anemoi_2_1, AnemoiEdOnBls12_377_2_1, ffi::ANEMOI_ED_ON_BLS12_377, 4, 2);
+impl_mi355x!(ed_on_bls12_377, anemoi_2_1, AnemoiEdOnBls12_377_2_1, ffi::ANEMOI_ED_ON_BLS12_377, 4, 2);
 #[cfg(feature = "ed_on_bls12_377")]
-impl_mi355x!(crate::ed_on_bls12_377::anemoi_4_3, AnemoiEdOnBls12_377_4_3, ffi::ANEMOI_ED_ON_BLS12_377, 4, 4);
+impl_mi355x!(ed_on_bls12_377, anemoi_4_3, AnemoiEdOnBls12_377_4_3, ffi::ANEMOI_ED_ON_BLS12_377, 4, 4);
 #[cfg(feature = "jubjub")]
-impl_mi355x!(crate::jubjub::anemoi_2_1, AnemoiJubjub_2_1, ffi::ANEMOI_JUBJUB, 4, 2);
+impl_mi355x!(jubjub, anemoi_2_1, AnemoiJubjub_2_1, ffi::ANEMOI_JUBJUB, 4, 2);
 #[cfg(feature = "jubjub")]
-impl_mi355x!(crate::jubjub::anemoi_4_3, AnemoiJubjub_4_3, ffi::ANEMOI_JUBJUB, 4, 4);
+impl_mi355x!(jubjub, anemoi_4_3, AnemoiJubjub_4_3, ffi::ANEMOI_JUBJUB, 4, 4);
 #[cfg(feature = "pallas")]
-impl_mi355x!(crate::pallas::anemoi_2_1, AnemoiPallas_2_1, ffi::ANEMOI_PALLAS, 4, 2);
+impl_mi355x!(pallas, anemoi_2_1, AnemoiPallas_2_1, ffi::ANEMOI_PALLAS, 4, 2);
 #[cfg(feature = "pallas")]
-impl_mi355x!(crate::pallas::anemoi_4_3, AnemoiPallas_4_3, ffi::ANEMOI_PALLAS, 4, 4);
+impl_mi355x!(pallas, anemoi_4_3, AnemoiPallas_4_3, ffi::ANEMOI_PALLAS, 4, 4);
 #[cfg(feature = "vesta")]
-impl_mi355x!(crate::vesta::anemoi_2_1, AnemoiVesta_2_1, ffi::ANEMOI_VESTA, 4, 2);
+impl_mi355x!(vesta, anemoi_2_1, AnemoiVesta_2_1, ffi::ANEMOI_VESTA, 4, 2);
 #[cfg(feature = "vesta")]
-impl_mi355x!(crate::vesta::anemoi_4_3, AnemoiVesta_4_3, ffi::ANEMOI_VESTA, 4, 4);
+impl_mi355x!(vesta, anemoi_4_3, AnemoiVesta_4_3, ffi::ANEMOI_VESTA, 4, 4);

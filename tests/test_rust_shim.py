@@ -55,7 +55,7 @@ def test_patch_uses_existing_symbols_and_covers_all_instances(params):
     for name, args in used:
         nargs = len([a for a in args.split(",") if a.strip()])
         assert ext[name] == nargs, (name, nargs, ext[name])
-    inst = re.findall(r"impl_mi355x!\(crate::([a-z0-9_]+)::anemoi_(2_1|4_3), (\w+), ffi::(ANEMOI_[A-Z0-9_]+), (\d), (\d)\);", patch)
+    inst = re.findall(r"impl_mi355x!\(([a-z0-9_]+), anemoi_(2_1|4_3), (\w+), ffi::(ANEMOI_[A-Z0-9_]+), (\d), (\d)\);", patch)
     assert len(inst) == 14
     lib = open(LIB_RS).read()
     seen = set()
