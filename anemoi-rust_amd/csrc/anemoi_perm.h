@@ -299,23 +299,28 @@ __device__ __forceinline__ void fe_select(typename A::Fe& r, bool take_a, const 
 //   s0 += g s1 ; s1 += g s0 ; s3 += g s2 ; s2 += g s3 ; swap(s2, s3) ; s2 += s0 ; s3 += s1 ; s0 += s2 ; s1 += s3
 template <class F, class A>
 __device__ __forceinline__ void mds_pair(typename A::Fe& x, typename A::Fe& y, bool odd) {
-  typename A::Fe p, t, s;
-  fe_exchange<A>(p, x);  // even lanes: s0 += g * s1
+  // The reference's four generator statements are two independent chains, (s0 += g s1 ; s1 += g s0) on the x
+  // row and (s3 += g s2 ; s2 += g s3) on the y row.  The first statement of each chain belongs to a different
+  // lane of the pair (s0: even lane's x, s3: odd lane's y), and so does the second (s1: odd lane's x, s2: even
+  // lane's y) -- so each lane runs ONE g-multiplication per step on its own operand, two per layer instead
+  // of four (for the fields whose g * x is a full Montgomery product that is 2 of ~320 products per round).
+  typename A::Fe px, py, p, t, s;
+  fe_exchange<A>(px, x);
+  fe_exchange<A>(py, y);
+  fe_select<A>(p, odd, py, px);  // even: s1 (the odd lane's x); odd: s2 (the even lane's y)
   A::mul_g(t, p);
   A::add(s, x, t);
-  fe_select<A>(x, !odd, s, x);
-  fe_exchange<A>(p, x);  // odd lanes: s1 += g * s0 (the updated one)
+  fe_select<A>(x, !odd, s, x);   // even: s0 += g s1
+  A::add(s, y, t);
+  fe_select<A>(y, odd, s, y);    // odd:  s3 += g s2
+  fe_exchange<A>(px, x);
+  fe_exchange<A>(py, y);
+  fe_select<A>(p, odd, px, py);  // odd: the updated s0 (even lane's x); even: the updated s3 (odd lane's y)
   A::mul_g(t, p);
   A::add(s, x, t);
-  fe_select<A>(x, odd, s, x);
-  fe_exchange<A>(p, y);  // odd lanes: s3 += g * s2
-  A::mul_g(t, p);
+  fe_select<A>(x, odd, s, x);    // odd:  s1 += g s0
   A::add(s, y, t);
-  fe_select<A>(y, odd, s, y);
-  fe_exchange<A>(p, y);  // even lanes: s2 += g * s3 (the updated one)
-  A::mul_g(t, p);
-  A::add(s, y, t);
-  fe_select<A>(y, !odd, s, y);
+  fe_select<A>(y, !odd, s, y);   // even: s2 += g s3
   fe_exchange<A>(p, y);  // swap(s2, s3)
   y = p;
   A::add(y, y, x);  // s2 += s0 ; s3 += s1
