@@ -77,3 +77,18 @@ def test_one_small_batch_policy_everywhere():
     m = re.search(r"MI355X_MIN_BATCH\s*=\s*(\d+)", doc)
     assert m and int(m.group(1)) == thr
     assert "batch of one" not in doc.lower() or "not rerouted" in doc.lower()
+
+
+def test_rust_text_is_at_least_well_bracketed():
+    """No rustc here: the cheapest syntax check there is -- (), [], {} balance outside strings, chars and comments."""
+    for path in (LIB_RS, PATCH):
+        text = open(path).read()
+        text = re.sub(r"//[^\n]*", "", text)
+        text = re.sub(r'"(?:\\.|[^"\\])*"', '""', text)
+        stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+        for ch in text:
+            if ch in "([{":
+                stack.append(ch)
+            elif ch in pairs:
+                assert stack and stack.pop() == pairs[ch], path
+        assert not stack, path
