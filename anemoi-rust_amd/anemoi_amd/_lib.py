@@ -100,6 +100,12 @@ _SIGS = {
     "anemoi_generic_hash_field_batch": ([_gip, _int, _u64p, _sz, _sz, _u64p, _int], _int),
     "anemoi_generic_hash_bytes_batch": ([_gip, _int, _u8p, _sz, _sz, _u64p, _int], _int),
     "anemoi_exp_alpha_batch": ([_int, _int, _u64p, _sz, _int], _int),
+    "anemoi_generic_prepare": ([_gip, _int, ctypes.POINTER(_vp)], _int),
+    "anemoi_generic_destroy": ([_vp], _int),
+    "anemoi_generic_permutation_dev": ([_vp, _vp, _sz, _vp], _int),
+    "anemoi_generic_jive_compress_k_dev": ([_vp, _int, _vp, _vp, _sz, _vp], _int),
+    "anemoi_generic_hash_field_dev": ([_vp, _int, _vp, _sz, _sz, _vp, _vp], _int),
+    "anemoi_generic_hash_bytes_dev": ([_vp, _int, _vp, _sz, _sz, _vp, _vp], _int),
     "anemoi_from_montgomery_dev": ([_int, _vp, _vp, _sz, _vp], _int),
 }
 for _name, (_args, _res) in _SIGS.items():
@@ -438,6 +444,13 @@ class GenericAnemoi:
         self._inst = _GenericInstance(self.field, num_columns, num_rounds, _p64(self._c), _p64(self._d),
                                       _p64(self._m) if self._m is not None else None)
 
+    def _inst_ref(self):
+        return ctypes.byref(self._inst)
+
+    def prepare(self, device=None):
+        """anemoi_generic_prepare: constants uploaded and converted once -> PreparedGenericAnemoi (device pointers)"""
+        return PreparedGenericAnemoi(self, self.device if device is None else device)
+
     def permutation_batch(self, states):
         s = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, self.width, self.limbs).copy()
         _check(lib.anemoi_generic_permutation_batch(ctypes.byref(self._inst), _p64(s), len(s), self.device))
@@ -465,3 +478,39 @@ class GenericAnemoi:
         _check(lib.anemoi_generic_hash_bytes_batch(ctypes.byref(self._inst), rate, _p8(m) if m.size else None,
                                                    m.shape[1], m.shape[0], _p64(out), self.device))
         return out
+
+
+class PreparedGenericAnemoi:
+    """A run-time instance whose constants live on the device in the kernels' own form (anemoi_generic_prepare).
+    The methods take raw device pointers (ints) and a HIP stream handle (int, 0 = the NULL stream), like the
+    library's other `_dev` entry points; the caller's current device must be `device`."""
+
+    def __init__(self, generic, device):
+        self.generic, self.device = generic, device
+        self.limbs, self.width = generic.limbs, generic.width
+        h = ctypes.c_void_p()
+        _check(lib.anemoi_generic_prepare(generic._inst_ref(), device, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            _check(lib.anemoi_generic_destroy(self._h))
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def permutation_dev(self, d_states, n, stream=0):
+        _check(lib.anemoi_generic_permutation_dev(self._h, d_states, n, stream))
+
+    def compress_k_dev(self, k, d_in, d_out, n, stream=0):
+        _check(lib.anemoi_generic_jive_compress_k_dev(self._h, k, d_in, d_out, n, stream))
+
+    def hash_field_dev(self, rate, d_elems, elems_per_msg, n, d_out, stream=0):
+        _check(lib.anemoi_generic_hash_field_dev(self._h, rate, d_elems, elems_per_msg, n, d_out, stream))
+
+    def hash_bytes_dev(self, rate, d_msgs, msg_len, n, d_out, stream=0):
+        _check(lib.anemoi_generic_hash_bytes_dev(self._h, rate, d_msgs, msg_len, n, d_out, stream))

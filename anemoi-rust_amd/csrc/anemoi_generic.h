@@ -13,8 +13,10 @@
 //     the hard-coded arms the host passes the matrix the arm applies (capi.hip builtin_mds; that the
 //     arms and their matrices agree statement by statement is checked in oracle/anemoi_ref.py and
 //     tests/test_oracle.py), so results are bit-identical to the arm;
-//   * constants arrive in the C-ABI's Montgomery form and are converted on use (2 + 2c products per
-//     round next to the ~c * 475 of the S-boxes).
+//   * constants arrive in the C-ABI's Montgomery form and are converted ONCE into the kernels' own form
+//     (k_generic_prepare: A::NL limbs in R' Montgomery form, padded to whole uint4) -- per shard by the
+//     host-pointer entry points, per anemoi_generic_prepare() handle for the device-pointer ones.  Round 2
+//     converted them on every use: c + 2 extra products per lane per round.
 //
 // Loose bounds (units of p, mont29.h): matrix entries and state < 2 -> products < 2 -> row sums
 // < 2c <= 32 (c <= 16) -> y'' < 64 -> settled before the PHT step so that x'' < 6, y'' < 4; both are
@@ -30,11 +32,29 @@ namespace anemoi {
 constexpr int kMaxGenericColumns = 16;
 
 struct GenericConsts {
-  const uint32_t* ark_c;  // [rounds][cols] ABI elements (device memory)
+  const uint32_t* ark_c;  // [rounds][cols] elements in the kernels' internal form (device memory), see below
   const uint32_t* ark_d;
-  const uint32_t* mds;    // [cols][cols] ABI elements, row-major
+  const uint32_t* mds;    // [cols][cols], row-major
   int cols, rounds;
 };
+
+// internal-form constant: A::NL limbs (R' Montgomery form, < 2p) in generic_stride<A>() words, zero padded
+template <class A>
+constexpr int generic_stride() {
+  return (A::NL + 3) / 4 * 4;
+}
+
+template <class A>
+__device__ __forceinline__ void load_k(typename A::Fe& v, const uint32_t* __restrict__ p) {
+  uint32_t w[generic_stride<A>()];
+#pragma unroll
+  for (int q = 0; q < generic_stride<A>() / 4; q++) {
+    const uint4 t = ((const uint4*)p)[q];
+    w[4 * q] = t.x, w[4 * q + 1] = t.y, w[4 * q + 2] = t.z, w[4 * q + 3] = t.w;
+  }
+#pragma unroll
+  for (int i = 0; i < A::NL; i++) v.l[i] = w[i];
+}
 
 template <class A>
 __device__ __forceinline__ void load_abi(typename A::Fe& v, const uint32_t* __restrict__ p) {
@@ -89,7 +109,7 @@ __device__ __forceinline__ void mds_cols(typename A::Fe& x, typename A::Fe& y, c
   const int c = geo.c;
 #pragma nounroll
   for (int j = 0; j < c; j++) {
-    load_abi<A>(m, gc.mds + size_t(geo.col * c + j) * A::NABI);
+    load_k<A>(m, gc.mds + size_t(geo.col * c + j) * generic_stride<A>());
     fe_from_lane<A>(p, x, geo.base + j);
     A::mul(t, p, m);
     A::add(nx, nx, t);
@@ -115,14 +135,28 @@ __device__ __forceinline__ void permutation_cols(typename A::Fe& x, typename A::
 #pragma nounroll
   for (int r = 0; r < gc.rounds; r++) {
     typename A::Fe k;
-    load_abi<A>(k, gc.ark_c + size_t(r * geo.c + geo.col) * A::NABI);  // ark_layer, src/traits.rs:111-125
+    load_k<A>(k, gc.ark_c + size_t(r * geo.c + geo.col) * generic_stride<A>());  // ark_layer, src/traits.rs:111-125
     A::add(x, x, k);
-    load_abi<A>(k, gc.ark_d + size_t(r * geo.c + geo.col) * A::NABI);
+    load_k<A>(k, gc.ark_d + size_t(r * geo.c + geo.col) * generic_stride<A>());
     A::add(y, y, k);
     mds_cols<F, A>(x, y, gc, geo);
     flystel<F, A, WIN>(x, y, pc, tab);
   }
   mds_cols<F, A>(x, y, gc, geo);
+}
+
+// ABI elements -> internal-form constants, one element per lane (run once per instance / shard)
+template <int FIELD>
+__global__ __launch_bounds__(kBlock) void k_generic_prepare(const uint32_t* __restrict__ abi, uint32_t* __restrict__ out,
+                                                            size_t count) {
+  using A = ArithFor<FIELD>;
+  const size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= count) return;
+  typename A::Fe v;
+  load_abi<A>(v, abi + i * A::NABI);
+  uint32_t* o = out + i * generic_stride<A>();
+#pragma unroll
+  for (int l = 0; l < generic_stride<A>(); l++) o[l] = l < A::NL ? v.l[l] : 0u;
 }
 
 template <int FIELD>

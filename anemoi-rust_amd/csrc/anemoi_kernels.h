@@ -741,6 +741,9 @@ struct FieldOps {
   hipError_t (*generic_sponge)(int bytes, const void* d_src, size_t per_msg, size_t n, void* d_out, int rate,
                                GenericConsts gc, PermConsts pc, hipStream_t s);
   hipError_t (*exp_alpha)(int inverse, void* d_elems, size_t n, PermConsts pc, hipStream_t s);
+  // run-time-instance constants: ABI elements -> the kernels' internal form (generic_stride words each)
+  hipError_t (*generic_prepare)(const void* d_abi, void* d_out, size_t count, hipStream_t s);
+  int generic_stride;
   // items one full wave of workgroups of a batch kernel processes on the current device (every CU at its
   // resident-workgroup limit, from the occupancy API): the chunk quantum of the host-pointer pipeline
   size_t (*wave_items)(int kind, int width, int num_cus);
@@ -910,6 +913,12 @@ struct Launch {
     return hipGetLastError();
   }
 
+  static hipError_t generic_prepare(const void* abi, void* out, size_t count, hipStream_t s) {
+    if (!count) return hipSuccess;
+    k_generic_prepare<FIELD><<<grid_for(count), kBlock, 0, s>>>((const uint32_t*)abi, (uint32_t*)out, count);
+    return hipGetLastError();
+  }
+
   template <class K>
   static size_t resident_items(K kernel, size_t lds, int items_per_wg, int num_cus) {
     int nb = 0;
@@ -939,7 +948,8 @@ struct Launch {
   static const FieldOps* ops() {
     static const FieldOps o{F::L64,       F::kChunk,    F::kRounds21,        F::kRounds43, F::kG, F::kAlpha, F::kName,
                             host_consts,  permutation,  jive,                sponge,       sponge_seg,   sponge_ragged, mont_convert,
-                            merkle_climb, generic_permutation, generic_jive, generic_sponge, exp_alpha, wave_items};
+                            merkle_climb, generic_permutation, generic_jive, generic_sponge, exp_alpha,
+                            generic_prepare, generic_stride<A>(), wave_items};
     return &o;
   }
 };

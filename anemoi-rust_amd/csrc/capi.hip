@@ -55,14 +55,27 @@ size_t elem_bytes(int field) { return size_t(anemoi::field_ops(field)->limbs64) 
 
 // Chunk quantum of a batch kernel on `dev`: items per full wave of workgroups (occupancy API; cached).
 size_t quantum_of(int field, int kind, int width, int dev) {
+  // per device: the occupancy query answers for the CURRENT device, and the CU count differs between
+  // partition modes (SPX / CPX) and parts
+  if (const char* e = getenv("ANEMOI_TEST_QUANTUM")) {  // test knob: small quanta make small batches multi-chunk
+    const unsigned long long v = strtoull(e, nullptr, 10);
+    if (v) return size_t(v);
+  }
   static std::mutex mu;
-  static size_t cache[anemoi::kNumFields][5][2] = {};
+  static size_t cache[rt::kMaxDevices][anemoi::kNumFields][5][2] = {};
   const int wi = width == 2 ? 0 : 1;
+  if (dev < 0 || dev >= rt::kMaxDevices) dev = 0;
   std::lock_guard<std::mutex> lock(mu);
-  size_t& q = cache[field][kind][wi];
-  if (!q) q = anemoi::field_ops(field)->wave_items(kind, width, rt::device_cus(dev));
+  size_t& q = cache[dev][field][kind][wi];
+  if (!q) {
+    DeviceGuard guard;
+    (void)hipSetDevice(dev);
+    q = anemoi::field_ops(field)->wave_items(kind, width, rt::device_cus(dev));
+  }
   return q;
 }
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Borrows a lane on `dev` and runs body(lane); waits for the lane's streams if body failed.
 template <class Body>
@@ -88,37 +101,72 @@ int check_generic(const anemoi_generic_instance* inst) {
   return ANEMOI_OK;
 }
 
-// Uploads an instance's constants into lane scratch buffer 0 (stream-ordered on the lane's kernel stream).
-int upload_generic(Lane& ln, const anemoi_generic_instance* inst, anemoi::GenericConsts* gc) {
+// Device bytes an instance's constants need: the ABI elements as uploaded (ark_c | ark_d | mds) followed by the
+// same elements in the kernels' internal form (FieldOps::generic_stride words each).
+struct GenericLayout {
+  size_t ab, mb, elems, abi_bytes, total;
+};
+GenericLayout generic_layout(const anemoi_generic_instance* inst) {
   const FieldOps* ops = anemoi::field_ops(inst->field);
   const size_t eb = elem_bytes(inst->field), c = size_t(inst->num_columns);
-  const size_t ab = size_t(inst->num_rounds) * c * eb, mb = c * c * eb;
-  int rc = ln.scratch[0].reserve(2 * ab + mb);
+  GenericLayout g;
+  g.ab = size_t(inst->num_rounds) * c * eb;
+  g.mb = c * c * eb;
+  g.elems = 2 * size_t(inst->num_rounds) * c + c * c;
+  g.abi_bytes = align_up(2 * g.ab + g.mb, 256);
+  g.total = g.abi_bytes + g.elems * size_t(ops->generic_stride) * 4;
+  return g;
+}
+
+// Uploads an instance's constants into `d_buf` (generic_layout().total bytes) and converts them, on stream s.
+// `canon` (the small-integer matrix of a hard-coded arm) is the source of an asynchronous copy: every exit,
+// also the failing ones, waits for the stream before the vector dies.
+int build_generic_consts(const anemoi_generic_instance* inst, char* d_buf, hipStream_t st, anemoi::GenericConsts* gc) {
+  const FieldOps* ops = anemoi::field_ops(inst->field);
+  const size_t eb = elem_bytes(inst->field), c = size_t(inst->num_columns);
+  const GenericLayout g = generic_layout(inst);
+  char* b = d_buf;
+  uint32_t* internal = (uint32_t*)(d_buf + g.abi_bytes);
+  std::vector<uint64_t> canon;
+  auto body = [&]() -> int {
+    HIP_TRY(hipMemcpyAsync(b, inst->ark_c, g.ab, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b + g.ab, inst->ark_d, g.ab, hipMemcpyHostToDevice, st));
+    if (inst->mds) {
+      HIP_TRY(hipMemcpyAsync(b + 2 * g.ab, inst->mds, g.mb, hipMemcpyHostToDevice, st));
+    } else {
+      std::vector<uint64_t> small;
+      if (!host::builtin_mds(inst->num_columns, uint64_t(ops->generator), &small)) return ANEMOI_ERR_ARG;
+      canon.assign(c * c * (eb / 8), 0);
+      for (size_t i = 0; i < c * c; i++) canon[i * (eb / 8)] = small[i];
+      HIP_TRY(hipMemcpyAsync(b + 2 * g.ab, canon.data(), g.mb, hipMemcpyHostToDevice, st));
+      HIP_TRY(ops->mont_convert(1, b + 2 * g.ab, b + 2 * g.ab, c * c, st));
+    }
+    HIP_TRY(ops->generic_prepare(b, internal, g.elems, st));
+    return ANEMOI_OK;
+  };
+  int rc = body();
+  const hipError_t e = hipStreamSynchronize(st);
   if (rc) return rc;
-  char* b = (char*)ln.scratch[0].p;
-  HIP_TRY(hipMemcpyAsync(b, inst->ark_c, ab, hipMemcpyHostToDevice, ln.s_k));
-  HIP_TRY(hipMemcpyAsync(b + ab, inst->ark_d, ab, hipMemcpyHostToDevice, ln.s_k));
-  std::vector<uint64_t> canon;  // must outlive the asynchronous copy below: synchronised before returning
-  if (inst->mds) {
-    HIP_TRY(hipMemcpyAsync(b + 2 * ab, inst->mds, mb, hipMemcpyHostToDevice, ln.s_k));
-  } else {
-    std::vector<uint64_t> small;
-    if (!host::builtin_mds(inst->num_columns, uint64_t(ops->generator), &small)) return ANEMOI_ERR_ARG;
-    canon.assign(c * c * (eb / 8), 0);
-    for (size_t i = 0; i < c * c; i++) canon[i * (eb / 8)] = small[i];
-    HIP_TRY(hipMemcpyAsync(b + 2 * ab, canon.data(), mb, hipMemcpyHostToDevice, ln.s_k));
-    HIP_TRY(ops->mont_convert(1, b + 2 * ab, b + 2 * ab, c * c, ln.s_k));
-  }
-  HIP_TRY(hipStreamSynchronize(ln.s_k));
-  gc->ark_c = (const uint32_t*)b;
-  gc->ark_d = (const uint32_t*)(b + ab);
-  gc->mds = (const uint32_t*)(b + 2 * ab);
+  if (e != hipSuccess) return rt::fail_hip(e, "hipStreamSynchronize(constants of a run-time instance)");
+  const size_t stride = size_t(ops->generic_stride), per = size_t(inst->num_rounds) * c;
+  gc->ark_c = internal;
+  gc->ark_d = internal + per * stride;
+  gc->mds = internal + 2 * per * stride;
   gc->cols = inst->num_columns;
   gc->rounds = inst->num_rounds;
   return ANEMOI_OK;
 }
 
-// host-pointer batch over a run-time instance: constants are uploaded per shard, then `launch`
+// per shard of a host-pointer call: the constants live in lane scratch buffer 0
+int upload_generic(Lane& ln, const anemoi_generic_instance* inst, anemoi::GenericConsts* gc) {
+  int rc = ln.scratch[0].reserve(generic_layout(inst).total);
+  if (rc) return rc;
+  return build_generic_consts(inst, (char*)ln.scratch[0].p, ln.s_k, gc);
+}
+
+// Host-pointer batch over a run-time instance: the constants are uploaded once per shard, then the items go
+// through the chunked pipeline (copy of chunk c + 1 under the kernel of chunk c, three chunks on the device).
+// One state occupies `cols` lanes, so a full wave of workgroups is the fixed-instance quantum / cols.
 template <class LaunchFn>
 int generic_batch(const anemoi_generic_instance* inst, int device, size_t n, const void* in, size_t in_per_item,
                   void* out, size_t out_per_item, LaunchFn launch) {
@@ -130,18 +178,36 @@ int generic_batch(const anemoi_generic_instance* inst, int device, size_t n, con
       PermConsts pc;
       int rc = upload_generic(ln, inst, &gc);
       if (!rc) rc = get_consts(inst->field, 2, &pc);  // exponent schedule of the field
-      if (!rc) rc = ln.scratch[1].reserve(count * in_per_item);
-      if (!rc && out != in) rc = ln.scratch[2].reserve(count * out_per_item);
       if (rc) return rc;
-      void* di = ln.scratch[1].p;
-      void* o = out != in ? ln.scratch[2].p : di;
-      HIP_TRY(hipMemcpyAsync(di, (const char*)in + first * in_per_item, count * in_per_item, hipMemcpyHostToDevice,
-                             ln.s_k));
-      HIP_TRY(launch(di, o, count, gc, pc, ln.s_k));
-      HIP_TRY(hipMemcpyAsync((char*)out + first * out_per_item, o, count * out_per_item, hipMemcpyDeviceToHost,
-                             ln.s_k));
-      HIP_TRY(hipStreamSynchronize(ln.s_k));
-      return ANEMOI_OK;
+      size_t quantum = quantum_of(inst->field, anemoi::kKindJive, 2, dev) / size_t(inst->num_columns);
+      if (quantum < 64) quantum = 64;
+      const host::ChunkPlan cp = host::plan_chunks(count, quantum, in_per_item > out_per_item ? in_per_item : out_per_item,
+                                                   rt::chunk_target_bytes());
+      const char* src = (const char*)in + first * in_per_item;
+      char* dst = (char*)out + first * out_per_item;
+      auto first_of = [&](size_t c) { return c * cp.chunk_items; };
+      auto count_of = [&](size_t c) { return c + 1 == cp.chunks ? count - first_of(c) : cp.chunk_items; };
+      return rt::pipeline_staged(
+          ln, cp.chunks,
+          [&](size_t c) { return rt::StagedChunk{count_of(c) * in_per_item, count_of(c) * out_per_item, 0}; },
+          [&](size_t c, char* h) -> int {
+            memcpy(h, src + first_of(c) * in_per_item, count_of(c) * in_per_item);
+            return ANEMOI_OK;
+          },
+          [&](size_t c, void* di, void* dout, void*, hipStream_t st) -> int {
+            // in place (permutation): the kernel works on the input buffer; its result is copied to d_out
+            if (out == in) {
+              HIP_TRY(launch(di, di, count_of(c), gc, pc, st));
+              HIP_TRY(hipMemcpyAsync(dout, di, count_of(c) * out_per_item, hipMemcpyDeviceToDevice, st));
+            } else {
+              HIP_TRY(launch(di, dout, count_of(c), gc, pc, st));
+            }
+            return ANEMOI_OK;
+          },
+          [&](size_t c, const char* h) -> int {
+            memcpy(dst + first_of(c) * out_per_item, h, count_of(c) * out_per_item);
+            return ANEMOI_OK;
+          });
     });
   });
 }
@@ -300,11 +366,16 @@ int sponge_segments(Lane& ln, int field, int width, int bytes, const char* src, 
   if (!rc) rc = ln.pipeline_streams();
   if (!rc) rc = ln.scratch[0].reserve(n * width * eb);   // carried sponge state
   if (!rc) rc = ln.scratch[1].reserve(n * eb);           // digests
-  for (int s = 0; !rc && s < rt::kSlots; s++) {
-    rc = ln.slot[s].d_in.reserve(n * seg_bytes);
-    if (!rc) rc = ln.slot[s].p_in.reserve(n * seg_bytes);
-  }
+  for (int s = 0; !rc && s < rt::kSlots; s++) rc = ln.slot[s].d_in.reserve(n * seg_bytes);
   if (rc) return rc;
+  // Pinned staging is an optimisation, as in rt::pipeline: without it (ANEMOI_HOST_STAGING=direct, or the host
+  // cannot pin that much) the segment goes up as ONE strided copy straight from the caller's memory.
+  bool staged = rt::staging_mode() == 1;
+  for (int s = 0; staged && s < rt::kSlots; s++)
+    if (ln.slot[s].p_in.reserve(n * seg_bytes)) {
+      staged = false;
+      for (auto& sl : ln.slot) sl.p_in.release();
+    }
   for (size_t c = 0; c < nseg; c++) {
     rt::Slot& sl = ln.slot[c % rt::kSlots];
     const size_t off = c * seg_bytes, len = c + 1 == nseg ? per_msg_bytes - off : seg_bytes;
@@ -314,9 +385,13 @@ int sponge_segments(Lane& ln, int field, int width, int bytes, const char* src, 
       HIP_TRY(hipEventSynchronize(sl.e_in));
       HIP_TRY(hipStreamWaitEvent(ln.s_in, sl.e_k, 0));
     }
-    char* stage = (char*)sl.p_in.p;
-    for (size_t i = 0; i < n; i++) memcpy(stage + i * len, src + i * per_msg_bytes + off, len);   // strided gather
-    HIP_TRY(hipMemcpyAsync(sl.d_in.p, stage, n * len, hipMemcpyHostToDevice, ln.s_in));
+    if (staged) {
+      char* stage = (char*)sl.p_in.p;
+      for (size_t i = 0; i < n; i++) memcpy(stage + i * len, src + i * per_msg_bytes + off, len);   // strided gather
+      HIP_TRY(hipMemcpyAsync(sl.d_in.p, stage, n * len, hipMemcpyHostToDevice, ln.s_in));
+    } else {
+      HIP_TRY(hipMemcpy2DAsync(sl.d_in.p, len, src + off, per_msg_bytes, len, n, hipMemcpyHostToDevice, ln.s_in));
+    }
     HIP_TRY(hipEventRecord(sl.e_in, ln.s_in));
     HIP_TRY(hipStreamWaitEvent(ln.s_k, sl.e_in, 0));
     anemoi::SpongeSeg seg{(uint32_t*)ln.scratch[0].p, off / elem_in, per_msg, c == 0 ? 1 : 0, c + 1 == nseg ? 1 : 0};
@@ -549,8 +624,8 @@ int anemoi_generic_jive_compress_k_batch(const anemoi_generic_instance* inst, in
   // the reference's asserts (anemoi_4_3/hasher.rs:163-165): k <= width, k | width, k even
   if (!host::valid_generic_k(w, k)) return ANEMOI_ERR_ARG;
   if (n && (!in || !out)) return ANEMOI_ERR_ARG;
-  if ((const void*)in == (void*)out) return ANEMOI_ERR_ARG;
   const size_t eb = elem_bytes(inst->field);
+  if (host::ranges_overlap(in, n * eb * w, out, n * eb * (w / k))) return ANEMOI_ERR_ARG;
   return generic_batch(inst, device, n, in, eb * w, out, eb * (w / k),
                        [&](void* i, void* o, size_t cnt, anemoi::GenericConsts gc, PermConsts pc, hipStream_t s) {
                          return anemoi::field_ops(inst->field)->generic_jive(i, o, cnt, k, gc, pc, s);
@@ -579,6 +654,115 @@ int anemoi_generic_hash_field_batch(const anemoi_generic_instance* inst, int rat
 int anemoi_generic_hash_bytes_batch(const anemoi_generic_instance* inst, int rate, const uint8_t* msgs, size_t msg_len,
                                     size_t n, uint64_t* out, int device) {
   return generic_hash(inst, rate, 1, msgs, msg_len, n, out, device);
+}
+
+/* ---- run-time instances, device-pointer form ---- */
+
+struct anemoi_generic_handle {
+  uint32_t magic;
+  int field, cols, rounds, device;
+  void* blob;
+  anemoi::GenericConsts gc;
+};
+static constexpr uint32_t kHandleMagic = 0xA9E30C01u;
+
+int anemoi_generic_prepare(const anemoi_generic_instance* inst, int device, anemoi_generic_handle** handle) {
+  if (!handle) return ANEMOI_ERR_ARG;
+  *handle = nullptr;
+  int rc = check_generic(inst);
+  if (rc) return rc;
+  int ndev = 0;
+  if ((rc = rt::physical_devices(&ndev))) return rc;
+  if (device < 0 || device >= ndev) {
+    g_last_error = "device ordinal out of range";
+    return ANEMOI_ERR_DEVICE;
+  }
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(device));
+  PermConsts pc;
+  if ((rc = get_consts(inst->field, 2, &pc))) return rc;  // the field's exponent schedule, uploaded ahead of time
+  void* blob = nullptr;
+  if (hipMalloc(&blob, generic_layout(inst).total) != hipSuccess) {
+    (void)hipGetLastError();
+    g_last_error = "hipMalloc(constants of a run-time instance)";
+    return ANEMOI_ERR_ALLOC;
+  }
+  anemoi::GenericConsts gc;
+  rc = with_lane(device, [&](Lane& ln) { return build_generic_consts(inst, (char*)blob, ln.s_k, &gc); });
+  if (rc) {
+    (void)hipFree(blob);
+    return rc;
+  }
+  *handle = new anemoi_generic_handle{kHandleMagic, inst->field, inst->num_columns, inst->num_rounds, device, blob, gc};
+  return ANEMOI_OK;
+}
+
+int anemoi_generic_destroy(anemoi_generic_handle* h) {
+  if (!h) return ANEMOI_OK;
+  if (h->magic != kHandleMagic) return ANEMOI_ERR_ARG;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(h->device));
+  (void)hipFree(h->blob);
+  h->magic = 0;
+  delete h;
+  return ANEMOI_OK;
+}
+
+// the handle is valid, the current device is its device; fetches the field's exponent schedule
+static int check_handle(const anemoi_generic_handle* h, PermConsts* pc) {
+  if (!h || h->magic != kHandleMagic) return ANEMOI_ERR_ARG;
+  int cur = -1;
+  HIP_TRY(hipGetDevice(&cur));
+  if (cur != h->device) {
+    g_last_error = "the current device is not the device the handle was prepared on";
+    return ANEMOI_ERR_DEVICE;
+  }
+  return get_consts(h->field, 2, pc);
+}
+
+int anemoi_generic_permutation_dev(const anemoi_generic_handle* h, void* d_states, size_t n, void* stream) {
+  PermConsts pc;
+  int rc = check_handle(h, &pc);
+  if (rc) return rc;
+  if (n && !d_states) return ANEMOI_ERR_ARG;
+  HIP_TRY(anemoi::field_ops(h->field)->generic_permutation(d_states, n, h->gc, pc, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+int anemoi_generic_jive_compress_k_dev(const anemoi_generic_handle* h, int k, const void* d_in, void* d_out, size_t n,
+                                       void* stream) {
+  PermConsts pc;
+  int rc = check_handle(h, &pc);
+  if (rc) return rc;
+  const int w = 2 * h->cols;
+  if (!host::valid_generic_k(w, k)) return ANEMOI_ERR_ARG;
+  if (n && (!d_in || !d_out)) return ANEMOI_ERR_ARG;
+  const size_t eb = elem_bytes(h->field);
+  if (host::ranges_overlap(d_in, n * eb * w, d_out, n * eb * (w / k))) return ANEMOI_ERR_ARG;
+  HIP_TRY(anemoi::field_ops(h->field)->generic_jive(d_in, d_out, n, k, h->gc, pc, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+static int generic_hash_dev(const anemoi_generic_handle* h, int rate, int bytes, const void* d_src, size_t per_msg,
+                            size_t n, void* d_out, void* stream) {
+  PermConsts pc;
+  int rc = check_handle(h, &pc);
+  if (rc) return rc;
+  if (rate < 1 || rate >= 2 * h->cols) return ANEMOI_ERR_ARG;
+  if (n && (!d_out || (per_msg && !d_src))) return ANEMOI_ERR_ARG;
+  HIP_TRY(anemoi::field_ops(h->field)->generic_sponge(bytes, d_src, per_msg, n, d_out, rate, h->gc, pc,
+                                                      (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+int anemoi_generic_hash_field_dev(const anemoi_generic_handle* h, int rate, const void* d_elems, size_t elems_per_msg,
+                                  size_t n, void* d_out, void* stream) {
+  return generic_hash_dev(h, rate, 0, d_elems, elems_per_msg, n, d_out, stream);
+}
+
+int anemoi_generic_hash_bytes_dev(const anemoi_generic_handle* h, int rate, const void* d_msgs, size_t msg_len, size_t n,
+                                  void* d_out, void* stream) {
+  return generic_hash_dev(h, rate, 1, d_msgs, msg_len, n, d_out, stream);
 }
 
 int anemoi_exp_alpha_batch(int field, int inverse, uint64_t* elems, size_t n, int device) {
@@ -791,27 +975,37 @@ int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t* msgs, co
     if (offsets[i + 1] < offsets[i]) return ANEMOI_ERR_ARG;  // offsets must be non-decreasing
   if (offsets[n] > offsets[0] && !msgs) return ANEMOI_ERR_ARG;
   const size_t eb = elem_bytes(field);
-  static const uint8_t dummy[16] = {0};
+  // Chunked like the fixed-length batches (rt::pipeline_staged): cut at message boundaries near the chunk
+  // target, whole wavefronts of messages per chunk, offsets rebased to the chunk's first byte; the copy of
+  // chunk c + 1 runs under the kernel of chunk c and the device holds three chunks, not the batch.
+  // Staging of a chunk: [count + 1 offsets | pad to 256 B | the chunk's bytes].
+  const size_t per_wave = width == 2 ? size_t(anemoi::kBlock) : size_t(anemoi::kPairStates);
   return rt::for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
     if (!count) return ANEMOI_OK;
     return with_lane(dev, [&](Lane& ln) -> int {
-      const uint64_t base = offsets[first], bytes = offsets[first + count] - base;
-      std::vector<uint64_t> rel(count + 1);
-      for (size_t i = 0; i <= count; i++) rel[i] = offsets[first + i] - base;
-      rt::Buf &dm = ln.scratch[0], &dof = ln.scratch[1], &dd = ln.scratch[2];
-      int r = dm.reserve(bytes + 16);
-      if (!r) r = dof.reserve((count + 1) * 8);
-      if (!r) r = dd.reserve(count * eb);
-      if (r) return r;
-      hipStream_t s = ln.s_k;
-      HIP_TRY(hipMemcpyAsync(dm.p, bytes ? (const void*)(msgs + base) : (const void*)dummy, bytes ? bytes : 16,
-                             hipMemcpyHostToDevice, s));
-      HIP_TRY(hipMemcpyAsync(dof.p, rel.data(), (count + 1) * 8, hipMemcpyHostToDevice, s));
-      r = anemoi_hash_bytes_ragged_dev(field, width, dm.p, dof.p, count, dd.p, s);
-      if (r) return r;
-      HIP_TRY(hipMemcpyAsync((char*)out + first * eb, dd.p, count * eb, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));  // `rel` must outlive the copy-in
-      return ANEMOI_OK;
+      const uint64_t* off = offsets + first;
+      const size_t quantum = quantum_of(field, anemoi::kKindSponge, width, dev);
+      const std::vector<size_t> cuts = host::plan_ragged_chunks(off, count, rt::chunk_target_bytes(), per_wave, 4 * quantum);
+      auto cnt_of = [&](size_t c) { return cuts[c + 1] - cuts[c]; };
+      auto off_bytes = [&](size_t c) { return align_up((cnt_of(c) + 1) * 8, 256); };
+      auto msg_bytes = [&](size_t c) { return size_t(off[cuts[c + 1]] - off[cuts[c]]); };
+      return rt::pipeline_staged(
+          ln, cuts.size() - 1,
+          [&](size_t c) { return rt::StagedChunk{off_bytes(c) + msg_bytes(c) + 16, cnt_of(c) * eb, 0}; },
+          [&](size_t c, char* h) -> int {
+            uint64_t* rel = (uint64_t*)h;
+            const uint64_t base = off[cuts[c]];
+            for (size_t i = 0; i <= cnt_of(c); i++) rel[i] = off[cuts[c] + i] - base;
+            if (msg_bytes(c)) memcpy(h + off_bytes(c), msgs + base, msg_bytes(c));
+            return ANEMOI_OK;
+          },
+          [&](size_t c, void* di, void* dout, void*, hipStream_t st) -> int {
+            return anemoi_hash_bytes_ragged_dev(field, width, (char*)di + off_bytes(c), di, cnt_of(c), dout, st);
+          },
+          [&](size_t c, const char* h) -> int {
+            memcpy((char*)out + (first + cuts[c]) * eb, h, cnt_of(c) * eb);
+            return ANEMOI_OK;
+          });
     });
   });
 }
@@ -865,27 +1059,36 @@ int anemoi_merkle_verify_batch(int field, const uint64_t* leaves, const uint64_t
   if (depth > 63 || (n && (!leaves || !indices || !root || !ok || (depth && !paths)))) return ANEMOI_ERR_ARG;
   if (n == 0) return ANEMOI_OK;
   const size_t eb = elem_bytes(field);
+  // chunked (rt::pipeline_staged): a chunk's staging is [leaves | indices | paths], each part 256-byte aligned
   return rt::for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
     if (!count) return ANEMOI_OK;
     return with_lane(dev, [&](Lane& ln) -> int {
-      rt::Buf &dl = ln.scratch[0], &di = ln.scratch[1], &dp = ln.scratch[2], &dr = ln.scratch[3];
-      int r = dl.reserve(count * eb);
-      if (!r) r = di.reserve(count * 8);
-      if (!r) r = dp.reserve(count * depth * eb);
-      if (!r) r = dr.reserve(count * eb);
-      if (r) return r;
-      hipStream_t s = ln.s_k;
-      HIP_TRY(hipMemcpyAsync(dl.p, (const char*)leaves + first * eb, count * eb, hipMemcpyHostToDevice, s));
-      HIP_TRY(hipMemcpyAsync(di.p, indices + first, count * 8, hipMemcpyHostToDevice, s));
-      if (depth)
-        HIP_TRY(hipMemcpyAsync(dp.p, (const char*)paths + first * depth * eb, count * depth * eb, hipMemcpyHostToDevice, s));
-      r = anemoi_merkle_climb_dev(field, dl.p, di.p, dp.p, depth, count, dr.p, s);
-      if (r) return r;
-      std::vector<uint64_t> got(count * (eb / 8));
-      HIP_TRY(hipMemcpyAsync(got.data(), dr.p, count * eb, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      for (size_t i = 0; i < count; i++) ok[first + i] = memcmp(&got[i * (eb / 8)], root, eb) == 0 ? 1 : 0;
-      return ANEMOI_OK;
+      const size_t per_item = eb + 8 + size_t(depth) * eb;
+      const host::ChunkPlan cp = host::plan_chunks(count, quantum_of(field, anemoi::kKindJive, 2, dev), per_item,
+                                                   rt::chunk_target_bytes());
+      auto first_of = [&](size_t c) { return c * cp.chunk_items; };
+      auto count_of = [&](size_t c) { return c + 1 == cp.chunks ? count - first_of(c) : cp.chunk_items; };
+      auto o_idx = [&](size_t c) { return align_up(count_of(c) * eb, 256); };
+      auto o_path = [&](size_t c) { return o_idx(c) + align_up(count_of(c) * 8, 256); };
+      return rt::pipeline_staged(
+          ln, cp.chunks,
+          [&](size_t c) { return rt::StagedChunk{o_path(c) + count_of(c) * depth * eb + 16, count_of(c) * eb, 0}; },
+          [&](size_t c, char* h) -> int {
+            const size_t f = first + first_of(c), m = count_of(c);
+            memcpy(h, (const char*)leaves + f * eb, m * eb);
+            memcpy(h + o_idx(c), indices + f, m * 8);
+            if (depth) memcpy(h + o_path(c), (const char*)paths + f * depth * eb, m * depth * eb);
+            return ANEMOI_OK;
+          },
+          [&](size_t c, void* di, void* dout, void*, hipStream_t st) -> int {
+            char* b = (char*)di;
+            return anemoi_merkle_climb_dev(field, b, b + o_idx(c), b + o_path(c), depth, count_of(c), dout, st);
+          },
+          [&](size_t c, const char* h) -> int {
+            const size_t f = first + first_of(c);
+            for (size_t i = 0; i < count_of(c); i++) ok[f + i] = memcmp(h + i * eb, root, eb) == 0 ? 1 : 0;
+            return ANEMOI_OK;
+          });
     });
   });
 }
@@ -921,36 +1124,52 @@ int anemoi_merkle_verify_arity4_batch(int field, const uint64_t* leaves, const u
   if (n == 0) return ANEMOI_OK;
   const size_t eb = elem_bytes(field);
   const int quads = int(eb / 16);
+  // chunked like the binary form; per chunk the current nodes live in the slot's output buffer and the
+  // assembled 4-element states in the slot's scratch
   return rt::for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
     if (!count) return ANEMOI_OK;
     return with_lane(dev, [&](Lane& ln) -> int {
-      rt::Buf &dcur = ln.scratch[0], &di = ln.scratch[1], &dp = ln.scratch[2], &dst = ln.scratch[3];
-      int r = dcur.reserve(count * eb);
-      if (!r) r = di.reserve(count * 8);
-      if (!r) r = dp.reserve(count * depth4 * 3 * eb);
-      if (!r) r = dst.reserve(count * 4 * eb);
-      if (r) return r;
-      hipStream_t s = ln.s_k;
-      HIP_TRY(hipMemcpyAsync(dcur.p, (const char*)leaves + first * eb, count * eb, hipMemcpyHostToDevice, s));
-      HIP_TRY(hipMemcpyAsync(di.p, indices + first, count * 8, hipMemcpyHostToDevice, s));
-      if (depth4)
-        HIP_TRY(hipMemcpyAsync(dp.p, (const char*)paths + first * depth4 * 3 * eb, count * depth4 * 3 * eb,
-                               hipMemcpyHostToDevice, s));
       PermConsts pc;
-      if ((r = get_consts(field, 4, &pc))) return r;
-      const size_t threads = count * 4 * size_t(quads);
-      for (unsigned l = 0; l < depth4; l++) {
-        k_assemble4<<<unsigned((threads + 255) / 256), 256, 0, s>>>((const uint4*)dcur.p, (const uint4*)dp.p,
-                                                                     (const uint64_t*)di.p, l, depth4, count, quads,
-                                                                     (uint4*)dst.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(anemoi::field_ops(field)->jive(4, 4, dst.p, dcur.p, count, pc, s));
-      }
-      std::vector<uint64_t> got(count * (eb / 8));
-      HIP_TRY(hipMemcpyAsync(got.data(), dcur.p, count * eb, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      for (size_t i = 0; i < count; i++) ok[first + i] = memcmp(&got[i * (eb / 8)], root, eb) == 0 ? 1 : 0;
-      return ANEMOI_OK;
+      int r = get_consts(field, 4, &pc);
+      if (r) return r;
+      const size_t per_item = eb + 8 + size_t(depth4) * 3 * eb;
+      const host::ChunkPlan cp = host::plan_chunks(count, quantum_of(field, anemoi::kKindJive, 4, dev), per_item,
+                                                   rt::chunk_target_bytes());
+      auto first_of = [&](size_t c) { return c * cp.chunk_items; };
+      auto count_of = [&](size_t c) { return c + 1 == cp.chunks ? count - first_of(c) : cp.chunk_items; };
+      auto o_idx = [&](size_t c) { return align_up(count_of(c) * eb, 256); };
+      auto o_path = [&](size_t c) { return o_idx(c) + align_up(count_of(c) * 8, 256); };
+      return rt::pipeline_staged(
+          ln, cp.chunks,
+          [&](size_t c) {
+            return rt::StagedChunk{o_path(c) + count_of(c) * depth4 * 3 * eb + 16, count_of(c) * eb, count_of(c) * 4 * eb};
+          },
+          [&](size_t c, char* h) -> int {
+            const size_t f = first + first_of(c), m = count_of(c);
+            memcpy(h, (const char*)leaves + f * eb, m * eb);
+            memcpy(h + o_idx(c), indices + f, m * 8);
+            if (depth4) memcpy(h + o_path(c), (const char*)paths + f * depth4 * 3 * eb, m * depth4 * 3 * eb);
+            return ANEMOI_OK;
+          },
+          [&](size_t c, void* di, void* dout, void* dtmp, hipStream_t st) -> int {
+            char* b = (char*)di;
+            const size_t m = count_of(c), threads = m * 4 * size_t(quads);
+            if (depth4 == 0) HIP_TRY(hipMemcpyAsync(dout, b, m * eb, hipMemcpyDeviceToDevice, st));
+            for (unsigned l = 0; l < depth4; l++) {
+              // level 0 reads the leaves where they were staged; the following levels the previous level's nodes
+              k_assemble4<<<unsigned((threads + 255) / 256), 256, 0, st>>>(
+                  (const uint4*)(l == 0 ? (void*)b : dout), (const uint4*)(b + o_path(c)), (const uint64_t*)(b + o_idx(c)), l,
+                  depth4, m, quads, (uint4*)dtmp);
+              HIP_TRY(hipGetLastError());
+              HIP_TRY(anemoi::field_ops(field)->jive(4, 4, dtmp, dout, m, pc, st));
+            }
+            return ANEMOI_OK;
+          },
+          [&](size_t c, const char* h) -> int {
+            const size_t f = first + first_of(c);
+            for (size_t i = 0; i < count_of(c); i++) ok[f + i] = memcmp(h + i * eb, root, eb) == 0 ? 1 : 0;
+            return ANEMOI_OK;
+          });
     });
   });
 }

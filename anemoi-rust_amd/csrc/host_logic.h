@@ -22,11 +22,19 @@ inline size_t shard_begin(size_t n, size_t i, size_t parts) {
   return q * i + (r * i) / parts;
 }
 
-// Merkle tree over 2^depth leaves (arity 2^arity_log) shared by at most `parts` workers: the largest
-// power of the arity that is <= parts and <= the leaf count.  Returns log_arity(#subtrees).
+// Merkle tree over arity^depth leaves (arity = 2^arity_log) shared by `parts` workers.  Returns
+// log_arity(#subtrees): the largest power of the arity that is <= parts and <= the leaf count -- or, when
+// the NEXT power is a whole multiple of `parts` (arity 4 on 2 or 8 GPUs: 4 or 16 subtrees), that one, so that
+// every worker gets the same number of subtrees instead of half of them idling (subtrees of one worker run
+// one after the other, rt::run_parts).
 inline unsigned subtree_levels(unsigned depth, unsigned arity_log, size_t parts) {
   unsigned lv = 0;
   while (lv + 1 <= depth && (size_t(1) << (arity_log * (lv + 1))) <= parts) lv++;
+  const size_t have = size_t(1) << (arity_log * lv);
+  if (have < parts && lv + 1 <= depth) {
+    const size_t next = size_t(1) << (arity_log * (lv + 1));
+    if (next % parts == 0) lv++;
+  }
   return lv;
 }
 
@@ -87,6 +95,31 @@ inline ChunkPlan plan_chunks(size_t n, size_t quantum, size_t in_bytes_per_item,
   if (q == 0) q = 1;
   const size_t items = q * quantum;
   return {items, (n + items - 1) / items};
+}
+
+// Chunk plan of a RAGGED batch (message i = bytes [off[i], off[i+1]) of one blob): cut at message boundaries
+// so that a chunk holds at most `target_bytes` of message bytes (a single longer message is a chunk of its
+// own), its message count a multiple of `align` (one wavefront's worth of messages: a chunk boundary inside
+// a wavefront would leave idle lanes) whenever it has at least `align` messages, and at most `max_items`
+// messages (many empty messages must not make an unbounded offsets table).  Returns the first message of
+// every chunk plus n at the end; every chunk is non-empty.
+inline std::vector<size_t> plan_ragged_chunks(const uint64_t* off, size_t n, size_t target_bytes, size_t align,
+                                              size_t max_items) {
+  std::vector<size_t> cuts;
+  if (align == 0) align = 1;
+  if (max_items < align) max_items = align;
+  size_t first = 0;
+  while (first < n) {
+    cuts.push_back(first);
+    size_t end = first;
+    while (end < n && end - first < max_items && off[end + 1] - off[first] <= target_bytes) end++;
+    if (end == first) end = first + 1;  // one message longer than the target
+    size_t cnt = end - first;
+    if (cnt >= align) cnt = cnt / align * align;
+    first += cnt;
+  }
+  cuts.push_back(n);
+  return cuts;
 }
 
 // ---- the reference's hard-coded mds_layer arms as small-integer matrices --------------------------

@@ -44,6 +44,20 @@ struct Arith29 {
     uint32_t l[NL];
   };
 
+  // A field constant as the `b` operand of a product.  The limbs are moved into VGPRs by volatile statements
+  // right where they are needed: written as plain assignments, hipcc hoists the 13 v_mov of `One` (settle) and of
+  // `g R'` (mul_g of the tight fields) out of the round loop and keeps 26 registers alive across the whole
+  // exponentiation -- that alone put the BLS12-377 kernels at 180 VGPRs = 2 waves per SIMD
+  // (tools/vgpr_liveness.py, profiles/r03/kernel_resources.csv).  13 v_mov per use is noise next to ~430
+  // instructions per product.
+  template <const uint32_t (&K)[NL], int I = 0>
+  __device__ static __forceinline__ void load_const(Fe& k) {
+    if constexpr (I < NL) {
+      asm volatile("v_mov_b32 %0, %1" : "=v"(k.l[I]) : "n"(K[I]));
+      load_const<K, I + 1>(k);
+    }
+  }
+
   // carry ripple: limbs back below 2^29 (the top limb keeps the excess; values stay < 2^(29 NL))
   __device__ static __forceinline__ void norm(Fe& r) {
 #pragma unroll
@@ -178,8 +192,7 @@ struct Arith29 {
   __device__ static __forceinline__ void mul_g(Fe& r, const Fe& x) {
     if constexpr (kTight) {
       Fe g;
-#pragma unroll
-      for (int i = 0; i < NL; i++) g.l[i] = L::GMont[i];
+      load_const<L::GMont>(g);
       mul(r, x, g);
     } else {
       uint64_t acc = 0;
@@ -195,8 +208,7 @@ struct Arith29 {
   // value-preserving reduction to < 2p: x * R' / R'
   __device__ static __forceinline__ void settle(Fe& x) {
     Fe one;
-#pragma unroll
-    for (int i = 0; i < NL; i++) one.l[i] = L::One[i];
+    load_const<L::One>(one);
     mul(x, x, one);
   }
 
@@ -252,15 +264,13 @@ struct Arith29 {
   __device__ static __forceinline__ void from_abi(Fe& r, const uint32_t (&w)[NABI]) {
     Fe k;
     repack_in(r, w);
-#pragma unroll
-    for (int i = 0; i < NL; i++) k.l[i] = L::In[i];
+    load_const<L::In>(k);
     mul(r, r, k);
   }
   // internal (any value < 2^12 p) -> canonical ABI element
   __device__ static __forceinline__ void to_abi(uint32_t (&w)[NABI], const Fe& a) {
     Fe k, t;
-#pragma unroll
-    for (int i = 0; i < NL; i++) k.l[i] = L::Out[i];
+    load_const<L::Out>(k);
     mul(t, a, k);
     canonical(t);
     repack_out(w, t);
@@ -269,8 +279,7 @@ struct Arith29 {
   __device__ static __forceinline__ void from_int(Fe& r, const uint32_t (&w)[NABI]) {
     Fe k;
     repack_in(r, w);
-#pragma unroll
-    for (int i = 0; i < NL; i++) k.l[i] = L::RR[i];
+    load_const<L::RR>(k);
     mul(r, r, k);
   }
 

@@ -87,7 +87,7 @@ struct Buf {
 };
 
 struct Slot {
-  Buf d_in, d_out, p_in, p_out;
+  Buf d_in, d_out, d_tmp, p_in, p_out;
   hipEvent_t e_in = nullptr, e_k = nullptr, e_out = nullptr;
 };
 
@@ -135,7 +135,7 @@ struct Lane {
   }
   void destroy() {
     for (auto& s : slot) {
-      s.d_in.release(), s.d_out.release(), s.p_in.release(), s.p_out.release();
+      s.d_in.release(), s.d_out.release(), s.d_tmp.release(), s.p_in.release(), s.p_out.release();
       if (s.e_in) (void)hipEventDestroy(s.e_in);
       if (s.e_k) (void)hipEventDestroy(s.e_k);
       if (s.e_out) (void)hipEventDestroy(s.e_out);
@@ -150,7 +150,7 @@ struct Lane {
     }
   }
   void trim() {
-    for (auto& s : slot) s.d_in.trim(), s.d_out.trim(), s.p_in.trim(), s.p_out.trim();
+    for (auto& s : slot) s.d_in.trim(), s.d_out.trim(), s.d_tmp.trim(), s.p_in.trim(), s.p_out.trim();
     for (auto& b : scratch) b.trim();
   }
 };
@@ -286,13 +286,23 @@ struct LaneGuard {
 inline int release_device(int dev) {
   DeviceCtx& c = g_ctx[dev];
   std::vector<Lane*> lanes;
+  std::vector<void*> blobs;
   {
+    // ONE critical section decides and invalidates: a caller that takes a lane after this point finds no
+    // ready instance and uploads fresh tables; nobody can still hold a PermConsts into the blobs freed below
+    // (they are only handed out under this mutex, to calls that hold a lane -- and none is out)
     std::lock_guard<std::mutex> lock(c.mu);
     if (c.lanes_out != 0) {
       g_last_error = "anemoi_release while calls are in flight on the device";
       return ANEMOI_ERR_ARG;
     }
     lanes.swap(c.idle);
+    for (int f = 0; f < kNumFields; f++)
+      for (int w = 0; w < 2; w++) {
+        if (c.blob[f][w]) blobs.push_back(c.blob[f][w]);
+        c.blob[f][w] = nullptr;
+        c.ready[f][w] = false;
+      }
   }
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(dev));
@@ -300,13 +310,7 @@ inline int release_device(int dev) {
     ln->destroy();
     delete ln;
   }
-  std::lock_guard<std::mutex> lock(c.mu);
-  for (int f = 0; f < kNumFields; f++)
-    for (int w = 0; w < 2; w++) {
-      if (c.blob[f][w]) (void)hipFree(c.blob[f][w]);
-      c.blob[f][w] = nullptr;
-      c.ready[f][w] = false;
-    }
+  for (void* b : blobs) (void)hipFree(b);
   return ANEMOI_OK;
 }
 
@@ -331,21 +335,25 @@ inline int shard_parts(int ndev) {
   return ndev;
 }
 
-// Runs `body(part, device, first, count)` for every part, one host thread per part; the first failure
-// (lowest part) is reported with its thread's error text.
+// Runs `body(part, device, first, count)` for every part: one host thread per DEVICE, which works through its
+// parts (part i belongs to device i % ndev) one after the other -- two big batches side by side on one GPU
+// only slow each other down.  The first failure (lowest part) is reported with its
+// thread's error text.
 template <class Body>
 int run_parts(int parts, int ndev, size_t n, Body body) {
   std::vector<int> rc(parts, ANEMOI_OK);
   std::vector<std::string> err(parts);
   std::vector<std::thread> th;
-  th.reserve(parts);
-  for (int i = 0; i < parts; i++) {
-    const size_t b = host::shard_begin(n, size_t(i), size_t(parts)), e = host::shard_begin(n, size_t(i) + 1, size_t(parts));
-    th.emplace_back([&, i, b, e] {
-      rc[i] = body(i, i % ndev, b, e - b);
-      if (rc[i] != ANEMOI_OK) err[i] = g_last_error;
+  const int workers = parts < ndev ? parts : ndev;
+  th.reserve(workers);
+  for (int w = 0; w < workers; w++)
+    th.emplace_back([&, w] {
+      for (int i = w; i < parts; i += ndev) {
+        const size_t b = host::shard_begin(n, size_t(i), size_t(parts)), e = host::shard_begin(n, size_t(i) + 1, size_t(parts));
+        rc[i] = body(i, w, b, e - b);
+        if (rc[i] != ANEMOI_OK) err[i] = g_last_error;
+      }
     });
-  }
   for (auto& t : th) t.join();
   for (int i = 0; i < parts; i++)
     if (rc[i] != ANEMOI_OK) {
@@ -370,6 +378,17 @@ int for_devices(int device, size_t n, Body body) {
   const int parts = shard_parts(ndev);
   if (parts == 1 || n < size_t(parts)) return body(0, size_t(0), n);
   return run_parts(parts, ndev, n, [&](int, int dev, size_t first, size_t count) { return body(dev, first, count); });
+}
+
+// Input bytes per chunk of the host-pointer pipelines.  ANEMOI_CHUNK_TARGET_BYTES is a test knob (read at every
+// call): small values make small batches run through many chunks, so the slot ring wraps in the tests.
+inline size_t chunk_target_bytes() {
+  const char* e = getenv("ANEMOI_CHUNK_TARGET_BYTES");
+  if (e && *e) {
+    const unsigned long long v = strtoull(e, nullptr, 10);
+    if (v) return size_t(v);
+  }
+  return kChunkTargetBytes;
 }
 
 // 0 = copy straight from / to the caller's memory (HIP stages pageable memory itself);
@@ -407,7 +426,7 @@ template <class LaunchFn>
 int pipeline(Lane& ln, size_t n, const char* in, size_t ipi, char* out, size_t opi, size_t quantum, LaunchFn launch,
              char* d_dst = nullptr) {
   const bool inplace = !d_dst && (const void*)in == (const void*)out;
-  const host::ChunkPlan cp = host::plan_chunks(n, quantum, ipi, kChunkTargetBytes);
+  const host::ChunkPlan cp = host::plan_chunks(n, quantum, ipi, chunk_target_bytes());
   if (cp.chunks == 0) return ANEMOI_OK;
   bool staged = staging_mode() == 1;
   // the caller's buffers are pinned already (e.g. a pinned tensor, hipHostRegister'ed memory): copy straight
@@ -497,6 +516,91 @@ int pipeline(Lane& ln, size_t n, const char* in, size_t ipi, char* out, size_t o
   if (rc) return rc;
   for (size_t c = cp.chunks > size_t(ns) ? cp.chunks - ns : 0; c < cp.chunks; c++)
     if ((rc = drain(c))) return rc;  // (in d_dst mode this also joins both kernel streams on the host)
+  return ANEMOI_OK;
+}
+
+// The same three-slot pipeline for calls whose chunks are not one array of equal items: several input arrays
+// (path verification: leaves, indices, paths), ragged messages (a byte blob plus offsets rebased per chunk), a
+// result that is consumed on the host (verification compares with the root).  The caller describes chunk c by
+// its staging sizes, writes its inputs into ONE contiguous staging buffer (`stage`), enqueues its kernels
+// (`launch`, on the stream it is given; `d_tmp` is per-slot device scratch) and consumes its outputs
+// (`finish`).  Staging is pinned memory of the lane; when that cannot be had (locked-memory limits) or
+// ANEMOI_HOST_STAGING=direct, pageable buffers take its place -- slower copies, same results.
+// Device footprint: three chunks.
+struct StagedChunk {
+  size_t in_bytes, out_bytes, tmp_bytes;
+};
+
+template <class Plan, class Stage, class Launch, class Finish>
+int pipeline_staged(Lane& ln, size_t chunks, Plan plan, Stage stage, Launch launch, Finish finish) {
+  if (chunks == 0) return ANEMOI_OK;
+  size_t max_in = 0, max_out = 0, max_tmp = 0;
+  for (size_t c = 0; c < chunks; c++) {
+    const StagedChunk sc = plan(c);
+    max_in = sc.in_bytes > max_in ? sc.in_bytes : max_in;
+    max_out = sc.out_bytes > max_out ? sc.out_bytes : max_out;
+    max_tmp = sc.tmp_bytes > max_tmp ? sc.tmp_bytes : max_tmp;
+  }
+  const int ns = chunks < size_t(kSlots) ? int(chunks) : kSlots;
+  bool pinned = staging_mode() == 1;
+  std::vector<char> pg_in[kSlots], pg_out[kSlots];  // pageable stand-ins for the pinned staging
+  if (chunks > 1) {
+    int rc = ln.pipeline_streams();
+    if (rc) return rc;
+  }
+  for (int i = 0; i < ns; i++) {
+    Slot& sl = ln.slot[i];
+    int rc = sl.d_in.reserve(max_in);
+    if (!rc) rc = sl.d_out.reserve(max_out);
+    if (!rc && max_tmp) rc = sl.d_tmp.reserve(max_tmp);
+    if (rc) return rc;
+    if (pinned && (sl.p_in.reserve(max_in) || sl.p_out.reserve(max_out))) {
+      pinned = false;
+      for (auto& s2 : ln.slot) s2.p_in.release(), s2.p_out.release();
+    }
+  }
+  if (!pinned)
+    for (int i = 0; i < ns; i++) pg_in[i].resize(max_in ? max_in : 1), pg_out[i].resize(max_out ? max_out : 1);
+  auto host_in = [&](int i) { return pinned ? (char*)ln.slot[i].p_in.p : pg_in[i].data(); };
+  auto host_out = [&](int i) { return pinned ? (char*)ln.slot[i].p_out.p : pg_out[i].data(); };
+  const bool single = chunks == 1;
+  auto copy_out = [&](size_t c) -> int {
+    const int i = int(c % ns);
+    Slot& sl = ln.slot[i];
+    const size_t bytes = plan(c).out_bytes;
+    hipStream_t so = single ? ln.s_k : ln.s_out;
+    if (!single) HIP_TRY(hipStreamWaitEvent(so, sl.e_k, 0));
+    if (bytes) HIP_TRY(hipMemcpyAsync(host_out(i), sl.d_out.p, bytes, hipMemcpyDeviceToHost, so));
+    HIP_TRY(hipEventRecord(sl.e_out, so));
+    return ANEMOI_OK;
+  };
+  auto drain = [&](size_t c) -> int {
+    const int i = int(c % ns);
+    HIP_TRY(hipEventSynchronize(ln.slot[i].e_out));
+    return finish(c, (const char*)host_out(i));
+  };
+  for (size_t c = 0; c < chunks; c++) {
+    const int i = int(c % ns);
+    Slot& sl = ln.slot[i];
+    int rc;
+    if (c >= size_t(ns) && (rc = drain(c - ns))) return rc;
+    const StagedChunk sc = plan(c);
+    if ((rc = stage(c, host_in(i)))) return rc;
+    hipStream_t si = single ? ln.s_k : ln.s_in;
+    if (sc.in_bytes) HIP_TRY(hipMemcpyAsync(sl.d_in.p, host_in(i), sc.in_bytes, hipMemcpyHostToDevice, si));
+    hipStream_t ks = single ? ln.s_k : ((c & 1) ? ln.s_k2 : ln.s_k);
+    if (!single) {
+      HIP_TRY(hipEventRecord(sl.e_in, si));
+      HIP_TRY(hipStreamWaitEvent(ks, sl.e_in, 0));
+    }
+    if ((rc = launch(c, sl.d_in.p, sl.d_out.p, sl.d_tmp.p, ks))) return rc;
+    if (!single) HIP_TRY(hipEventRecord(sl.e_k, ks));
+    if (c >= 1 && (rc = copy_out(c - 1))) return rc;
+  }
+  int rc = copy_out(chunks - 1);
+  if (rc) return rc;
+  for (size_t c = chunks > size_t(ns) ? chunks - ns : 0; c < chunks; c++)
+    if ((rc = drain(c))) return rc;
   return ANEMOI_OK;
 }
 

@@ -234,6 +234,24 @@ int anemoi_merkle_climb_dev(int field, const void *d_leaves, const void *d_index
 int anemoi_to_montgomery_dev(int field, const void *d_in, void *d_out, size_t count, void *stream);
 int anemoi_from_montgomery_dev(int field, const void *d_in, void *d_out, size_t count, void *stream);
 
+
+/* ---- run-time instances on device pointers (src/traits.rs:36-76, :136-304) ---------------------------
+ * anemoi_generic_prepare() uploads an instance's constants to `device` ONCE and converts them into the
+ * kernels' own form (the hard-coded arm's matrix included when mds == NULL); the handle then serves any
+ * number of asynchronous calls on buffers in that device's HBM.  The caller's current device must be the
+ * handle's device; the handle must outlive the work queued with it; anemoi_generic_destroy() frees it
+ * (after the caller has synchronised its streams).  Errors and argument rules as for the _batch forms. */
+typedef struct anemoi_generic_handle anemoi_generic_handle;
+int anemoi_generic_prepare(const anemoi_generic_instance *inst, int device, anemoi_generic_handle **handle);
+int anemoi_generic_destroy(anemoi_generic_handle *handle);
+int anemoi_generic_permutation_dev(const anemoi_generic_handle *handle, void *d_states, size_t n, void *stream);
+int anemoi_generic_jive_compress_k_dev(const anemoi_generic_handle *handle, int k, const void *d_in, void *d_out,
+                                       size_t n, void *stream);
+int anemoi_generic_hash_field_dev(const anemoi_generic_handle *handle, int rate, const void *d_elems,
+                                  size_t elems_per_msg, size_t n, void *d_out, void *stream);
+int anemoi_generic_hash_bytes_dev(const anemoi_generic_handle *handle, int rate, const void *d_msgs, size_t msg_len,
+                                  size_t n, void *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,8 +43,11 @@ static void test_shards() {
 static void test_subtrees() {
   CHECK(subtree_levels(24, 1, 8) == 3 && subtree_levels(24, 1, 7) == 2 && subtree_levels(24, 1, 1) == 0);
   CHECK(subtree_levels(2, 1, 8) == 2 && subtree_levels(0, 1, 8) == 0 && subtree_levels(1, 1, 1000) == 1);
-  CHECK(subtree_levels(10, 2, 8) == 1 && subtree_levels(10, 2, 16) == 2 && subtree_levels(10, 2, 3) == 0);
-  CHECK(subtree_levels(1, 2, 64) == 1);
+  // arity 4: 8 workers take 16 subtrees (2 each) rather than 4 (half of them idle); 2 workers take 4; 3 stay at 1
+  CHECK(subtree_levels(10, 2, 8) == 2 && subtree_levels(10, 2, 16) == 2 && subtree_levels(10, 2, 3) == 0);
+  CHECK(subtree_levels(10, 2, 2) == 1 && subtree_levels(10, 2, 4) == 1 && subtree_levels(10, 2, 5) == 1);
+  CHECK(subtree_levels(1, 2, 64) == 1 && subtree_levels(1, 2, 8) == 1 && subtree_levels(0, 2, 8) == 0);
+  CHECK(subtree_levels(24, 1, 6) == 2 && subtree_levels(24, 1, 3) == 1);   // binary: 8 % 6 != 0, 4 % 3 != 0
 }
 
 // brute-force trees over integers: node value = a hash-free stand-in (position-coded), only indices matter
@@ -108,6 +111,36 @@ static void test_overlap_and_chunks() {
   CHECK(plan_chunks(1000, 0, 8, 1 << 20).chunks >= 1);  // quantum 0 is treated as 1
 }
 
+// ragged chunk plan against its contract on random offset tables (incl. empty messages, one huge message)
+static void test_ragged_chunks() {
+  uint64_t seed = 12345;
+  auto rnd = [&]() { return seed = seed * 6364136223846793005ull + 1442695040888963407ull, seed >> 33; };
+  for (int trial = 0; trial < 400; trial++) {
+    const size_t n = rnd() % 700;
+    const size_t target = 1 + rnd() % 5000, align = trial % 3 == 0 ? 1 : 64, max_items = 64 + rnd() % 400;
+    std::vector<uint64_t> off(n + 1);
+    off[0] = rnd() % 100;   // offsets need not start at 0
+    for (size_t i = 0; i < n; i++) {
+      const unsigned kind = rnd() % 10;
+      const uint64_t len = kind == 0 ? 0 : kind == 1 ? rnd() % 20000 : rnd() % 200;
+      off[i + 1] = off[i] + len;
+    }
+    const std::vector<size_t> cuts = plan_ragged_chunks(off.data(), n, target, align, max_items);
+    CHECK(!cuts.empty() && cuts.back() == n && (n == 0 ? cuts.size() == 1 : cuts.front() == 0));
+    for (size_t c = 0; c + 1 < cuts.size(); c++) {
+      const size_t a = cuts[c], b = cuts[c + 1];
+      CHECK(a < b);                                              // non-empty, increasing
+      CHECK(b - a <= (max_items < align ? align : max_items));   // bounded offsets table
+      const uint64_t bytes = off[b] - off[a];
+      CHECK(bytes <= target || b - a == 1);                      // bounded staging, or one long message alone
+      if (b - a > align) CHECK((b - a) % align == 0);            // whole wavefronts
+      // greedy: the chunk could not have taken `align` more messages (unless it ran into max_items / the end)
+      if (b < n && b - a + align <= max_items && b - a >= align && b + align <= n)
+        CHECK(off[b + align] - off[a] > target);
+    }
+  }
+}
+
 static void test_mds_and_k() {
   std::vector<uint64_t> m;
   CHECK(!builtin_mds(0, 2, &m) && !builtin_mds(7, 2, &m));
@@ -143,6 +176,7 @@ int main() {
   test_subtrees();
   test_paths();
   test_overlap_and_chunks();
+  test_ragged_chunks();
   test_mds_and_k();
   std::printf("host logic ok\n");
   return 0;

@@ -422,3 +422,32 @@ def test_concurrent_callers_overlap_on_the_gpu(A, oracle):
     print("4 x %d latency-bound calls: serial %.1f ms, concurrent %.1f ms" % (reps, serial * 1e3, conc * 1e3))
     assert not errs
     assert conc < 0.6 * serial, (serial, conc)
+
+
+# ---------------------------------------------------------------- bench.py --gpus 2 over RCCL (needs >= 2 GPUs)
+
+def test_bench_two_ranks_over_rccl(A):
+    """The driver's N > 1 launch line, with the default control plane (torch.distributed "nccl" = RCCL): two ranks,
+    one GPU each, each verifying its 2^21-item shard of config 4 against the oracle goldens.  Test boxes have one
+    GPU, so this is skipped there -- NO hardware N > 1 number exists yet; the test is here so
+    that the first multi-GPU box exercises the RCCL branch of bench.py before the driver's scaling run does."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ANEMOI_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)   # a child process: no exec of this one
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["verified"]["ranks"] == 2 and line["verified"]["sha256_of_all_outputs"] is True
+    assert line["config"]["control_plane"] == "nccl" and line["config"]["parallelism"] == "shard2"
+    assert line["scaling"] == "weak" and line["value"] > 0

@@ -212,3 +212,66 @@ def test_generic_golden_vectors(A, R, oracle):
         assert dec(g.compress_k_batch(st, 2)) == ints(v["compress_k2"])
         msg = enc(v["message"]).reshape(1, -1, L)
         assert dec(g.hash_field_batch(msg, v["rate"])) == [int(v["hash_field"])]
+
+
+@pytest.mark.parametrize("field,cols,matrix", [("bls12_381", 1, None), ("bn_254", 2, None), ("jubjub", 3, None),
+                                               ("bls12_377", 5, None), ("vesta", 7, "random"), ("pallas", 16, "random")])
+def test_prepared_instances_on_device_pointers(A, R, oracle, field, cols, matrix):
+    """anemoi_generic_prepare + the `_dev` entry points (constants uploaded and converted once; buffers in HBM,
+    asynchronous on a stream): permutation, Jive and both sponges against the Python restatement of the
+    reference's arms (src/traits.rs:136-304) and against the host-pointer forms."""
+    import torch
+    gpu, ref, enc, dec = make_instance(A, R, oracle, field, cols, 3, seed=31 * cols + 5, with_matrix=matrix)
+    prep = gpu.prepare()
+    rng = random.Random(cols)
+    L, w = ref.limbs, 2 * cols
+    n = 64 // cols + 3
+    st_i = [[rng.randrange(ref.p) for _ in range(w)] for _ in range(n)]
+    st = np.stack([enc(s) for s in st_i])
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream()
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).reshape(-1)).to(dev)
+    back = lambda t, shape: t.cpu().numpy().view(np.uint64).reshape(shape)
+    d_st = to_dev(st)
+    torch.cuda.synchronize()
+    # permutation, in place
+    prep.permutation_dev(d_st.data_ptr(), n, stream.cuda_stream)
+    stream.synchronize()
+    got = back(d_st, (n, w, L))
+    assert (got == gpu.permutation_batch(st)).all()
+    for i in (0, n - 1):
+        assert dec(got[i]) == ref.permutation(list(st_i[i]))
+    # Jive for every admissible k; the reference's asserts for the others; overlapping buffers refused
+    d_in = to_dev(st)
+    for k in range(1, w + 2):
+        ok = k <= w and w % k == 0 and k % 2 == 0
+        d_out = torch.zeros(n * (w // k if ok else 1) * L, dtype=torch.int64, device=dev)
+        if ok:
+            prep.compress_k_dev(k, d_in.data_ptr(), d_out.data_ptr(), n, stream.cuda_stream)
+            stream.synchronize()
+            o = back(d_out, (n, w // k, L))
+            for i in (0, n // 2, n - 1):
+                assert dec(o[i]) == ref.compress_k(st_i[i], k)
+        else:
+            with pytest.raises(A.AnemoiError):
+                prep.compress_k_dev(k, d_in.data_ptr(), d_out.data_ptr(), n, stream.cuda_stream)
+    with pytest.raises(A.AnemoiError):
+        prep.compress_k_dev(2, d_in.data_ptr(), d_in.data_ptr() + 8 * L, n, stream.cuda_stream)
+    # sponges with rate = width - 1: elements and bytes
+    rate, ne = w - 1, 2 * (w - 1) + 1
+    el_i = [[rng.randrange(ref.p) for _ in range(ne)] for _ in range(n)]
+    el = np.stack([enc(e) for e in el_i])
+    d_el, d_dig = to_dev(el), torch.zeros(n * L, dtype=torch.int64, device=dev)
+    prep.hash_field_dev(rate, d_el.data_ptr(), ne, n, d_dig.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    assert (back(d_dig, (n, L)) == gpu.hash_field_batch(el.reshape(n, ne, L), rate)).all()
+    assert dec(back(d_dig, (n, L))[0]) == [ref.hash_field(el_i[0], rate)]
+    msgs = np.random.default_rng(cols).integers(0, 256, size=(n, 77), dtype=np.uint8)
+    d_m = torch.from_numpy(msgs).to(dev)
+    prep.hash_bytes_dev(rate, d_m.data_ptr(), 77, n, d_dig.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    assert (back(d_dig, (n, L)) == gpu.hash_batch(msgs, rate)).all()
+    with pytest.raises(A.AnemoiError):
+        prep.hash_bytes_dev(w, d_m.data_ptr(), 77, n, d_dig.data_ptr(), stream.cuda_stream)   # rate >= width
+    prep.close()
+    prep.close()   # idempotent

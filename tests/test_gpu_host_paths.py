@@ -1,0 +1,165 @@
+"""The host-pointer entry points that round 2 left outside the chunked pipeline -- the ragged sponge, batched
+path verification (binary and arity 4) and the run-time instances -- now go through rt::pipeline_staged
+(csrc/runtime.h): chunks cut at message / item boundaries, three chunks resident on the device.  These
+tests force MANY small chunks (ANEMOI_CHUNK_TARGET_BYTES, ANEMOI_TEST_QUANTUM: both read at every call) so
+that the three-slot ring wraps several times, in both staging modes, and compare every result with the
+oracle (reference semantics: src/<f>/anemoi_*/hasher.rs:19-91 for the sponge, :86-92 for merge, :162-179 for
+compress_k).  Bit-exact.  Run on the GPU box: pytest -m gpu.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import FIELD_IDS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def A():
+    import anemoi_amd
+    assert anemoi_amd.device_count() >= 1
+    return anemoi_amd
+
+
+@pytest.fixture(scope="module")
+def R():
+    import anemoi_ref
+    return anemoi_ref
+
+
+class env:
+    """environment knobs for the duration of a with-block (the library reads them at every call)"""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.prev = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("staging", ["pinned", "direct"])
+def test_ragged_sponge_through_many_chunks(A, oracle, staging):
+    """~700 messages of 0..300 bytes plus a few far longer than the chunk target, cut into chunks of <= 4 KB of
+    message bytes: every digest equals the oracle's hash of that message alone; the sharded form agrees."""
+    rng = np.random.default_rng(77)
+    for field, width in (("bn_254", 4), ("bls12_381", 2), ("jubjub", 2), ("bls12_377", 4)):
+        fid, inst = FIELD_IDS.index(field), A.Anemoi(field, width)
+        lens = [int(v) for v in rng.integers(0, 300, size=700)]
+        for pos, ln in ((5, 9000), (64, 4097), (65, 0), (333, 12345), (699, 5000)):
+            lens[pos] = ln
+        msgs = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for n in lens]
+        whole = inst.hash_ragged(msgs)                      # one chunk (default target)
+        with env(ANEMOI_CHUNK_TARGET_BYTES=4096, ANEMOI_HOST_STAGING=staging):
+            got = inst.hash_ragged(msgs)
+            with env(ANEMOI_VIRTUAL_DEVICES=3):
+                many = A.Anemoi(field, width, device=A.ALL_DEVICES).hash_ragged(msgs)
+        assert (got == whole).all() and (many == whole).all(), (field, width)
+        for i in list(range(0, 700, 7)) + [5, 64, 65, 333, 699]:
+            assert (got[i] == oracle.hash_bytes(fid, width, msgs[i])).all(), (field, width, i, lens[i])
+        # all-empty batch and a batch of one long message
+        with env(ANEMOI_CHUNK_TARGET_BYTES=4096, ANEMOI_HOST_STAGING=staging):
+            assert (inst.hash_ragged([b""] * 200) == 0).all()
+            one = inst.hash_ragged([msgs[333]])
+        assert (one[0] == whole[333]).all()
+
+
+@pytest.mark.parametrize("staging", ["pinned", "direct"])
+def test_path_verification_through_many_chunks(A, oracle, R, staging):
+    """5 000 (leaf, index, path) triples of a depth-6 tree, every 13th one tampered with, verified in chunks of
+    128 items: the accept / reject pattern is exactly the tampering pattern.  Binary and arity-4 trees."""
+    rng = random.Random(5)
+    for field, arity in (("jubjub", 2), ("bls12_381", 2), ("bn_254", 4), ("pallas", 4)):
+        width = 2 if arity == 2 else 4
+        fid, inst = FIELD_IDS.index(field), A.Anemoi(field, width)
+        depth = 6 if arity == 2 else 3
+        nleaf = arity ** depth
+        I = R.Instance(field, width)
+        leaves = oracle.ints_to_mont(fid, [rng.randrange(I.p) for _ in range(nleaf)])
+        if arity == 2:
+            levels = inst.merkle_tree(leaves, depth)
+            path_of = lambda i: inst.merkle_path(levels, depth, i)
+            verify = inst.merkle_verify_batch
+        else:
+            levels = inst.merkle_tree_arity4(leaves, depth)
+            path_of = lambda i: inst.merkle_path_arity4(levels, depth, i)
+            verify = inst.merkle_verify_arity4_batch
+        root = levels[-1][0]
+        all_paths = np.stack([path_of(i) for i in range(nleaf)])
+        n = 5000
+        idx = np.array([rng.randrange(nleaf) for _ in range(n)])
+        sel, paths = leaves[idx].copy(), all_paths[idx].copy()
+        bad = np.zeros(n, dtype=bool)
+        for i in range(0, n, 13):
+            bad[i] = True
+            kind = (i // 13) % 3
+            if kind == 0:
+                sel[i, 0] ^= np.uint64(1)                                  # tampered leaf
+            elif kind == 1:
+                paths[i].reshape(-1)[rng.randrange(paths[i].size)] ^= np.uint64(4)   # tampered sibling
+            else:
+                idx[i] ^= 1                                                # right leaf, wrong slot
+        whole = verify(sel, idx, paths, depth, root)
+        with env(ANEMOI_CHUNK_TARGET_BYTES=1, ANEMOI_TEST_QUANTUM=128, ANEMOI_HOST_STAGING=staging):
+            got = verify(sel, idx, paths, depth, root)
+            with env(ANEMOI_VIRTUAL_DEVICES=3):
+                sharded = A.Anemoi(field, width, device=A.ALL_DEVICES)
+                many = (sharded.merkle_verify_batch if arity == 2 else sharded.merkle_verify_arity4_batch)(
+                    sel, idx, paths, depth, root)
+        assert (np.asarray(got, dtype=bool) == ~bad).all(), (field, arity)
+        assert (np.asarray(whole, dtype=bool) == ~bad).all() and (np.asarray(many, dtype=bool) == ~bad).all()
+
+
+@pytest.mark.parametrize("staging", ["pinned", "direct"])
+def test_run_time_instances_through_many_chunks(A, R, oracle, staging):
+    """A 3-column run-time instance over 1 500 states in chunks of 64 states: permutation (in place), Jive and
+    the sponge equal the one-chunk run, and a sample equals the Python restatement of the reference's arms."""
+    from test_gpu_generic import make_instance
+    field, cols = "jubjub", 3
+    gpu, ref, enc, dec = make_instance(A, R, oracle, field, cols, 3, seed=4242)
+    rng = random.Random(9)
+    w, n = 2 * cols, 1500
+    st_i = [[rng.randrange(ref.p) for _ in range(w)] for _ in range(n)]
+    st = np.stack([enc(s) for s in st_i])
+    msgs = np.random.default_rng(3).integers(0, 256, size=(n, 100), dtype=np.uint8)
+    whole_p, whole_j, whole_h = gpu.permutation_batch(st), gpu.compress_k_batch(st, 2), gpu.hash_batch(msgs, w - 1)
+    with env(ANEMOI_CHUNK_TARGET_BYTES=1, ANEMOI_TEST_QUANTUM=64 * cols, ANEMOI_HOST_STAGING=staging):
+        got_p, got_j, got_h = gpu.permutation_batch(st), gpu.compress_k_batch(st, 2), gpu.hash_batch(msgs, w - 1)
+    assert (got_p == whole_p).all() and (got_j == whole_j).all() and (got_h == whole_h).all()
+    for i in range(0, n, 97):
+        assert dec(got_p[i]) == ref.permutation(list(st_i[i]))
+        assert dec(got_j[i]) == ref.compress_k(st_i[i], 2)
+    # overlapping input / output of the run-time Jive is refused like the fixed-instance one (partial overlap too)
+    flat = np.zeros(n * w * ref.limbs + 64, dtype=np.uint64)
+    from anemoi_amd import _lib
+    inp, outp = flat[:n * w * ref.limbs], flat[8:8 + n * cols * ref.limbs]
+    rc = A.lib.anemoi_generic_jive_compress_k_batch(gpu._inst_ref(), 2, inp.ctypes.data_as(_lib._u64p),
+                                                    outp.ctypes.data_as(_lib._u64p), n, 0)
+    assert rc == -3
+
+
+def test_sponge_segments_without_pinned_staging(A, oracle):
+    """ANEMOI_HOST_STAGING=direct: the segment-fed sponge uploads each segment as one strided copy straight from
+    the caller's memory instead of gathering into pinned staging (it used to ignore the knob, and to fail when
+    pinning failed).  Same digests as the oracle."""
+    rng = np.random.default_rng(5)
+    fid, inst = FIELD_IDS.index("bn_254"), A.Anemoi("bn_254", 4)
+    n, unit = 50, 3 * inst.chunk
+    msgs = rng.integers(0, 256, size=(n, 7 * unit + 11), dtype=np.uint8)
+    with env(ANEMOI_SPONGE_SEGMENT_BYTES=n * unit * 2, ANEMOI_HOST_STAGING="direct"):
+        got = inst.hash_batch(msgs)
+    assert (got == oracle.hash_bytes_batch(fid, 4, msgs, threads=4)).all()

@@ -12,8 +12,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "anemoi-rust_amd", "anemoi_amd"))
 import numpy as np
 import torch
+import buildinfo  # noqa: E402  (multiply-add counts per compression, from the generated assembly and schedules)
+
+# peak v_mad_u64_u32 lane-operations per second: 1024 SIMDs x 16 lanes per clock at the nominal 2.4 GHz (the boxes
+# run at 2.30-2.36 GHz under this load: GRBM_GUI_ACTIVE in profiles/rNN/pmc_*.json), so alu_frac here is a lower bound
+PEAK_LANE_MAD = 1024 * 16 * 2.4e9
 
 
 def main():
@@ -53,8 +59,10 @@ def main():
         d_in, d_out = states(n, width, limbs), torch.empty(n * limbs * (width // 2), dtype=torch.int64, device=dev)
         ms = timed(lambda: check(lib.anemoi_jive_compress_k_dev(field, width, 2, d_in.data_ptr(), d_out.data_ptr(), n,
                                                                 stream.cuda_stream)))
+        mad = buildinfo.mad_per_compression(field, width)
         out[name] = {"ms": ms, "compress_per_s": n / ms * 1e3, "modmul_per_s": n * modmul / ms * 1e3,
-                     "algorithmic_GBps": n * limbs * 8 * (width + width // 2) / ms / 1e6}
+                     "algorithmic_GBps": n * limbs * 8 * (width + width // 2) / ms / 1e6,
+                     "alu_frac": n * mad / (ms / 1e3) / PEAK_LANE_MAD}
 
     def check(rc):
         assert rc == 0, rc
@@ -73,9 +81,15 @@ def main():
     dig = torch.empty(nmsg * 4, dtype=torch.int64, device=dev)
     ms = timed(lambda: check(lib.anemoi_hash_bytes_dev(2, 4, msgs.data_ptr(), 10240, nmsg, dig.data_ptr(),
                                                        stream.cuda_stream)), reps=2)
+    # per message: 111 permutations on a lane pair + 331 element decodes (one product each, on both lanes)
+    mad3 = 111 * buildinfo.mad_per_permutation(2, 4) + 2 * 331 * buildinfo.limb_layout(2)["mul_mad"]
+    flat43 = out["extra_bn254_4_3_x2^20"]["compress_per_s"]
     out["cfg3_bn254_4_3_sponge_10KB_x2^%d" % (13 if args.quick else 16)] = {
         "ms": ms, "messages_per_s": nmsg / ms * 1e3, "permutations_per_s": nmsg * 111 / ms * 1e3,
-        "modmul_per_s": nmsg * 954156 / ms * 1e3, "algorithmic_GBps": nmsg * 10272 / ms / 1e6}
+        "modmul_per_s": nmsg * 954156 / ms * 1e3, "algorithmic_GBps": nmsg * 10272 / ms / 1e6,
+        "alu_frac": nmsg * mad3 / (ms / 1e3) / PEAK_LANE_MAD,
+        # permutations per second against the flat BN-254 4-3 Jive rate of this run (one permutation per compression)
+        "fraction_of_flat_rate": (nmsg * 111 / ms * 1e3) / flat43}
 
     # config 5: Jubjub Merkle tree, one GPU's subtree (depth 21 of the depth-24 tree; 2^21 leaves)
     depth = 17 if args.quick else 21
@@ -84,8 +98,12 @@ def main():
     root = torch.empty(4, dtype=torch.int64, device=dev)
     ms = timed(lambda: check(lib.anemoi_merkle_root_dev(4, leaves.data_ptr(), depth, scratch.data_ptr(), root.data_ptr(),
                                                         stream.cuda_stream)), reps=2)
+    merges = (1 << depth) - 1
     out["cfg5_jubjub_merkle_depth%d_subtree" % depth] = {
-        "ms": ms, "merges_per_s": ((1 << depth) - 1) / ms * 1e3, "algorithmic_GBps": 96 * ((1 << depth) - 1) / ms / 1e6}
+        "ms": ms, "merges_per_s": merges / ms * 1e3, "algorithmic_GBps": 96 * merges / ms / 1e6,
+        "alu_frac": merges * buildinfo.mad_per_compression(4, 2) / (ms / 1e3) / PEAK_LANE_MAD,
+        # merges per second against the flat Jubjub 2-1 Jive rate of this run: the tree's top levels are latency-bound
+        "fraction_of_flat_rate": (merges / ms * 1e3) / out["extra_jubjub_2_1_x2^20"]["compress_per_s"]}
     for k, v in out.items():
         print("%-44s %s" % (k, json.dumps({a: (round(b, 3) if b < 1e4 else float("%.4g" % b)) for a, b in v.items()})))
     print(json.dumps(out))

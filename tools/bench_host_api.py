@@ -18,10 +18,13 @@ import torch
 import anemoi_amd as A
 from anemoi_amd import synth
 
-sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [20, 24]
+sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or ([20, 24] if len(sys.argv) == 1 else [])
 fid = A.field_id("bls12_381")
 inst = A.Anemoi("bls12_381", 2)
 inst.compress_batch(synth.states("bls12_381", 2, 1, 0, 4096))  # warm-up: constants, a lane
+
+
+s = torch.cuda.current_stream()
 
 
 def median(ts):
@@ -98,6 +101,90 @@ if "cfg3" in sys.argv or len(sys.argv) == 1:
         t = median(ts[1:]) * 1e3
         print("  host-pointer, %-18s: %.1f ms -> %.3f x the resident rate (first call %.1f ms)" % (label, t, resident / t, ts[0] * 1e3))
     os.environ.pop("ANEMOI_SPONGE_SEGMENT_BYTES", None)
+
+# A 640 MiB ragged batch (2^19 BN-254 4-3 messages of 1 024 .. 1 536 bytes, unsorted) through
+# anemoi_hash_bytes_ragged_batch, which now runs on the chunked pipeline (chunks cut at message boundaries, offsets
+# rebased per chunk, three chunks on the device) next to the same launch on a blob that is already in HBM.
+if "ragged" in sys.argv or len(sys.argv) == 1:
+    rng = np.random.default_rng(1)
+    nm = 1 << 19
+    lens = rng.integers(1024, 1537, size=nm).astype(np.uint64)
+    offs = np.zeros(nm + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    blob = rng.integers(0, 256, size=int(offs[-1]), dtype=np.uint8)
+    f3 = A.field_id("bn_254")
+    dig = np.empty((nm, 4), dtype=np.uint64)
+    d_b, d_off = torch.from_numpy(blob).to("cuda:0"), torch.from_numpy(offs.view(np.int64)).to("cuda:0")
+    d_o = torch.empty(nm * 4, dtype=torch.int64, device="cuda:0")
+    res = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        assert A.lib.anemoi_hash_bytes_ragged_dev(f3, 4, d_b.data_ptr(), d_off.data_ptr(), nm, d_o.data_ptr(), s.cuda_stream) == 0
+        b.record(s)
+        torch.cuda.synchronize()
+        res.append(a.elapsed_time(b))
+    resident = median(res[1:])
+    want = d_o.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    del d_b, d_off, d_o
+    torch.cuda.empty_cache()
+    print("ragged batch (2^19 messages, %.0f MiB, BN-254 4-3): device-resident kernel %.1f ms" % (blob.size / 2**20, resident))
+    for mode in ("pinned", "direct"):
+        os.environ["ANEMOI_HOST_STAGING"] = mode
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = A.lib.anemoi_hash_bytes_ragged_batch(f3, 4, blob.ctypes.data_as(A._lib._u8p), offs.ctypes.data_as(A._lib._u64p),
+                                                      nm, dig.ctypes.data_as(A._lib._u64p), 0)
+            ts.append(time.perf_counter() - t0)
+            assert rc == 0
+        assert (dig == want).all()
+        t = median(ts[1:]) * 1e3
+        print("  host-pointer, staging=%-6s: %.1f ms -> %.3f x the resident rate (first call %.1f ms)" % (mode, t, resident / t, ts[0] * 1e3))
+    os.environ.pop("ANEMOI_HOST_STAGING", None)
+    del blob, offs
+
+# 2^22 depth-24 authentication paths (Jubjub; 3.4 GB of host memory) through anemoi_merkle_verify_batch
+if "verify" in sys.argv or len(sys.argv) == 1:
+    nv, depth = 1 << 22, 24
+    fj = A.field_id("jubjub")
+    leaves = synth.elements("jubjub", 5, 0, nv).reshape(nv, 4)
+    base = synth.elements("jubjub", 6, 0, 1 << 16).reshape(-1, 4)
+    paths = np.ascontiguousarray(base[np.random.default_rng(2).integers(0, 1 << 16, size=nv * depth)]).reshape(nv, depth, 4)
+    idx = np.random.default_rng(3).integers(0, 1 << depth, size=nv).astype(np.uint64)
+    d_l, d_i = torch.from_numpy(leaves.view(np.int64)).to("cuda:0"), torch.from_numpy(idx.view(np.int64)).to("cuda:0")
+    d_p = torch.from_numpy(paths.view(np.int64).reshape(-1)).to("cuda:0")
+    d_r = torch.empty(nv * 4, dtype=torch.int64, device="cuda:0")
+    res = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        assert A.lib.anemoi_merkle_climb_dev(fj, d_l.data_ptr(), d_i.data_ptr(), d_p.data_ptr(), depth, nv, d_r.data_ptr(), s.cuda_stream) == 0
+        b.record(s)
+        torch.cuda.synchronize()
+        res.append(a.elapsed_time(b))
+    resident = median(res[1:])
+    roots = d_r.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    del d_l, d_i, d_p, d_r
+    torch.cuda.empty_cache()
+    root = roots[12345].copy()            # the one item that verifies
+    print("path verification (2^22 paths of depth 24, Jubjub): device-resident kernel %.1f ms" % resident)
+    ok = np.zeros(nv, dtype=np.uint8)
+    for mode in ("pinned", "direct"):
+        os.environ["ANEMOI_HOST_STAGING"] = mode
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            rc = A.lib.anemoi_merkle_verify_batch(fj, leaves.ctypes.data_as(A._lib._u64p), idx.ctypes.data_as(A._lib._u64p),
+                                                  paths.ctypes.data_as(A._lib._u64p), depth, nv, root.ctypes.data_as(A._lib._u64p),
+                                                  ok.ctypes.data_as(A._lib._u8p), 0)
+            ts.append(time.perf_counter() - t0)
+            assert rc == 0
+        assert ok[12345] == 1 and ok.sum() == (roots == root).all(axis=1).sum()
+        t = min(ts) * 1e3
+        print("  host-pointer, staging=%-6s: %.1f ms -> %.3f x the resident rate (first call %.1f ms)" % (mode, t, resident / t, ts[0] * 1e3))
+    os.environ.pop("ANEMOI_HOST_STAGING", None)
+    del leaves, paths, idx
 
 # concurrent callers: latency-bound calls (48 items = one wave-cooperative launch each) from 4 threads
 sts = [synth.states("bls12_381", 2, 77 + k, 0, 48) for k in range(4)]

@@ -184,7 +184,7 @@ def gen_sqr(nl, plimbs, n0inv, W, p=None):
     P = lambda i: "%%%d" % (nl + i)
     N0 = "%%%d" % (2 * nl)
     out = []
-    for j in range(nl):
+    for j in range(nl - 1):   # a2[nl-1] would never be read: the top limb is always the larger index of a pair
         out.append("v_lshlrev_b32 v%d, 1, %s" % (a2 + j, A(j)))
     xacc = [((treg + 2 + 1) & ~1) + 2 * i for i in range(CHAINS - 1)]
     col = Column(out, W, acc, treg, cz, xacc)
