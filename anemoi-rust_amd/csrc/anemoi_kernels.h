@@ -597,44 +597,52 @@ ANEMOI_KERNEL void k_merkle_climb(const uint4* __restrict__ leaves, const uint64
   block_store<Q>(lds, out, blk0, cnt);
 }
 
-// ---- wave-cooperative Jive 2-to-1 compression (one item per wavefront, coop29.h) -----------------------
-// Latency path: used for small batches (coop_max_items(): the top levels of a Merkle tree, a
-// single Jive::compress / Sponge::merge call).  Same round function and the same bound bookkeeping as
-// the lane-private kernels; the window table (5-bit window: 16 odd powers, one word per lane each)
-// sits in LDS.
-// Batches up to this many items take the cooperative kernel: measured on Merkle trees
-// (profiles/r01/merkle_cooperative_threshold_sweep.txt) the best cut is ~2048 items for the 14-limb
-// fields (depth-18 BLS12-381 tree 164.7 -> 120.9 ms) and ~1024 for the 9-limb ones (depth-21 Jubjub
-// tree 139.2 -> 132.8 ms).  ANEMOI_COOP_MAX overrides it (0 = always lane-private, a huge value =
-// always cooperative); the parity tests run both ways.
-inline size_t coop_max_items(int limbs29) {
-  static const long long env = [] {
-    const char* e = getenv("ANEMOI_COOP_MAX");
-    return e ? (long long)strtoull(e, nullptr, 10) : -1ll;
-  }();
-  if (env >= 0) return size_t(env);
-  return limbs29 >= 14 ? 2048 : 1024;
+// ---- wave-cooperative Jive 2-to-1 compression (coop29.h) ----------------------------------------------
+// Latency path: small batches (the top levels of a Merkle tree, a single Jive::compress / Sponge::merge call).
+// Same round function and the same bound bookkeeping as the lane-private kernels; the window table (F::kCoopWin
+// bits, one word per lane and entry) sits in LDS.  Two layouts of the same arithmetic:
+//   LPR = 16  FOUR items per wavefront, one per 16-lane DPP row; everything row-local (a_i and the quotient digit
+//             by DPP row broadcast, the digit computed on the VALU).  The shipped latency kernel: one BLS12-381
+//             compression 2.98 ms, Jubjub 1.44 ms, flat up to 4 096 items (one wavefront per SIMD).
+//   LPR = 64  ONE item per wavefront, a_i and the quotient digit through v_readlane -> SGPR -> scalar ALU (rounds
+//             1-2's latency kernel): 4.10 / 1.96 ms -- the scalar round trip costs more than the VALU digit, and a
+//             wavefront carries a quarter of the items.  Kept selectable (ANEMOI_COOP_MAX) for A/B and parity.
+// Cut-offs from the per-size sweep (tools/sweep_coop.py, profiles/r03/coop_kernel_sweep.txt): the row-cooperative
+// kernel wins up to 8 192 items on both limb counts (Jubjub 2.25 vs 2.41 ms, BLS12-381 4.82 vs 7.29 ms at 8 192;
+// lane-private from 16 384: 2.41 vs 3.98, 7.27 vs 8.81).  The knobs are read at every call; the parity tests force
+// each kernel for every size.
+inline size_t coop_max_items(int) {
+  if (const char* e = getenv("ANEMOI_COOP_MAX")) return size_t(strtoull(e, nullptr, 10));
+  return 0;
+}
+inline size_t coop4_max_items(int) {
+  if (const char* e = getenv("ANEMOI_COOP4_MAX")) return size_t(strtoull(e, nullptr, 10));
+  return 8192;
 }
 
-template <int FIELD>
+template <int FIELD, int LPR>
 __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                        size_t n, PermConsts pc) {
   using F = FieldC<FIELD>;
-  using C = Coop29<F>;
-  constexpr int NL = C::NL, NABI = C::NABI, R = F::kRounds21, E = 1 << (F::kCoopWin - 1);
+  using C = Coop29<F, LPR>;
+  constexpr int NL = C::NL, NABI = C::NABI, R = F::kRounds21, E = 1 << (F::kCoopWin - 1), PER = kBlock / LPR;
   __shared__ uint32_t tab[E * kBlock];
-  const uint32_t lane = threadIdx.x;
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR;
   const uint32_t pl = C::konst(C::L::P), kpl = C::konst(C::L::KP), delta = C::konst(C::L::Delta);
-  for (size_t item = blockIdx.x; item < n; item += gridDim.x) {
-    const uint32_t w0 = lane < NABI ? in[(item * 2 + 0) * NABI + lane] : 0u;
-    const uint32_t w1 = lane < NABI ? in[(item * 2 + 1) * NABI + lane] : 0u;
+  const size_t groups = (n + PER - 1) / PER;   // a wavefront works on PER consecutive items
+  for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const size_t want = g * PER + row;
+    const bool live = want < n;
+    const size_t item = live ? want : n - 1;   // rows beyond the batch redo the last item (all rows run the same code)
+    const uint32_t w0 = j < NABI ? in[(item * 2 + 0) * NABI + j] : 0u;
+    const uint32_t w1 = j < NABI ? in[(item * 2 + 1) * NABI + j] : 0u;
     const uint32_t e0 = C::from_abi(w0, pl), e1 = C::from_abi(w1, pl);
     uint32_t x = e0, y = e1;
 #pragma nounroll
     for (int r = 0; r <= R; r++) {
       if (r < R) {  // ark_layer (src/traits.rs:111-125)
-        x = C::add(x, lane < NL ? pc.coop_c[r * NL + lane] : 0u);
-        y = C::add(y, lane < NL ? pc.coop_d[r * NL + lane] : 0u);
+        x = C::add(x, j < NL ? pc.coop_c[r * NL + j] : 0u);
+        y = C::add(y, j < NL ? pc.coop_d[r * NL + j] : 0u);
       }
       // mds_layer, NUM_COLUMNS = 1 (src/traits.rs:136-142), then back below 2p
       y = C::add(y, x);
@@ -678,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
     // Jive feed-forward: state[0] + state[1] + elems[0] + elems[1] (anemoi_2_1/hasher.rs:102)
     const uint32_t s = C::add(C::add(x, y), C::add(e0, e1));
     const uint32_t o = C::to_abi(s, pl);
-    if (lane < NABI) out[item * NABI + lane] = o;
+    if (live && j < NABI) out[item * NABI + j] = o;
   }
 }
 
@@ -753,6 +761,30 @@ enum KernelKind { kKindPermutation = 0, kKindJive = 1, kKindSponge = 2, kKindCon
 
 const FieldOps* field_ops(int field);  // capi.hip
 
+// Launches that do not fill the machine (fewer workgroups than the CUs can hold at once: config 3's 2 048
+// wavefronts, the middle levels of a Merkle tree) run ONE long wavefront per workgroup from start to end, so the
+// time of the launch is the time of the fullest SIMD -- and the dispatcher does not spread workgroups evenly over
+// the CUs by itself.  Requesting just enough dynamic LDS that no CU can hold more than ceil(workgroups / CUs)
+// workgroups forces the even spread.  ANEMOI_BALANCE_LDS=0 switches it off (A/B; read at every call).
+inline size_t balanced_lds(size_t need, size_t workgroups, size_t natural_per_cu) {
+  if (const char* e = getenv("ANEMOI_BALANCE_LDS"))
+    if (e[0] == '0') return need;
+  static int cus_of[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return need;
+  if (!cus_of[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus_of[dev] = n;
+  }
+  const size_t cus = size_t(cus_of[dev]), k = (workgroups + cus - 1) / cus;   // workgroups per CU when spread evenly
+  if (k == 0 || k >= natural_per_cu) return need;
+  constexpr size_t kLdsPerCu = 160 * 1024, kGranule = 2048;
+  size_t lds = kLdsPerCu / (k + 1) / kGranule * kGranule + kGranule;   // smallest granule multiple that k + 1 of do not fit
+  if (lds > 65536) lds = 65536;                                         // the default per-workgroup limit
+  return lds > need ? lds : need;
+}
+
 inline unsigned grid_for(size_t n) { return unsigned((n + kBlock - 1) / kBlock); }
 inline unsigned pair_grid(size_t n) { return unsigned((n + kBlock / 2 - 1) / (kBlock / 2)); }  // 32 states per workgroup
 
@@ -823,30 +855,42 @@ struct Launch {
     if (!n) return hipSuccess;
     if (width == 2 && n <= coop_max_items(F::Coop::NL)) {  // latency path: one item per wavefront
       const unsigned g = n < 65536 ? unsigned(n) : 65536u;  // the kernel strides over items
-      k_jive2_coop<FIELD><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
+      k_jive2_coop<FIELD, 64><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
+    if (width == 2 && n <= coop4_max_items(F::Coop::NL)) {  // four items per wavefront, one per DPP row
+      const size_t groups = (n + 3) / 4;
+      const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      k_jive2_coop<FIELD, 16><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
+      return hipGetLastError();
+    }
+    constexpr size_t kNat = A::NL >= 13 ? 12 : 16;   // resident wavefronts per CU these kernels are built for
     if (width == 2)
-      k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+      k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, balanced_lds(lds_bytes<A, WIN, 2>(), grid_for(n), kNat), s>>>(
+          (const uint4*)in, (uint4*)out, n, pc);
     else if (k == 2)
-      k_jive_pair<FIELD, 2><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+      k_jive_pair<FIELD, 2><<<pair_grid(n), kBlock, balanced_lds(lds_bytes<A, WIN, 2>(), pair_grid(n), kNat), s>>>(
+          (const uint4*)in, (uint4*)out, n, pc);
     else
-      k_jive_pair<FIELD, 4><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
+      k_jive_pair<FIELD, 4><<<pair_grid(n), kBlock, balanced_lds(lds_bytes<A, WIN, 2>(), pair_grid(n), kNat), s>>>(
+          (const uint4*)in, (uint4*)out, n, pc);
     return hipGetLastError();
   }
 
   static hipError_t sponge_seg(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
                                SpongeSeg seg, hipStream_t s) {
     if (!n) return hipSuccess;
-    const size_t l = lds_bytes<A, WIN, 1>();
+    constexpr size_t kNat = A::NL >= 13 ? 12 : 16;
+    const size_t l = balanced_lds(lds_bytes<A, WIN, 1>(), grid_for(n), kNat);
+    const size_t lp = balanced_lds(lds_bytes<A, WIN, 2>(), pair_grid(n), kNat);
     if (width == 2 && bytes)
       k_sponge<FIELD, 2, true><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc, seg);
     else if (width == 2)
       k_sponge<FIELD, 2, false><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc, seg);
     else if (bytes)
-      k_sponge_pair<FIELD, true><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(src, per_msg, n, (uint4*)out, pc, seg);
+      k_sponge_pair<FIELD, true><<<pair_grid(n), kBlock, lp, s>>>(src, per_msg, n, (uint4*)out, pc, seg);
     else
-      k_sponge_pair<FIELD, false><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(src, per_msg, n, (uint4*)out, pc, seg);
+      k_sponge_pair<FIELD, false><<<pair_grid(n), kBlock, lp, s>>>(src, per_msg, n, (uint4*)out, pc, seg);
     return hipGetLastError();
   }
 

@@ -985,7 +985,11 @@ int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t* msgs, co
     return with_lane(dev, [&](Lane& ln) -> int {
       const uint64_t* off = offsets + first;
       const size_t quantum = quantum_of(field, anemoi::kKindSponge, width, dev);
-      const std::vector<size_t> cuts = host::plan_ragged_chunks(off, count, rt::chunk_target_bytes(), per_wave, 4 * quantum);
+      // at least half a wave of workgroups of messages per chunk (two chunks' kernels run side by side on the
+      // lane's two kernel streams), at most 8 chunk targets of bytes
+      const size_t target = rt::chunk_target_bytes();
+      const std::vector<size_t> cuts =
+          host::plan_ragged_chunks(off, count, target, per_wave, quantum / 2, 4 * quantum, 8 * target);
       auto cnt_of = [&](size_t c) { return cuts[c + 1] - cuts[c]; };
       auto off_bytes = [&](size_t c) { return align_up((cnt_of(c) + 1) * 8, 256); };
       auto msg_bytes = [&](size_t c) { return size_t(off[cuts[c + 1]] - off[cuts[c]]); };

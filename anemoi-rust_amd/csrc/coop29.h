@@ -1,5 +1,5 @@
-// coop29.h -- wave-cooperative Montgomery arithmetic: ONE field element per wavefront, one 29-bit
-// limb per lane.  This is the low-latency path (small batches, the top levels of a Merkle tree, a
+// coop29.h -- wave-cooperative Montgomery arithmetic: one 29-bit limb per lane, ONE field element per
+// wavefront (LPR = 64) or FOUR, one per 16-lane DPP row (LPR = 16: lane 16 r + j holds limb j of element r).  This is the low-latency path (small batches, the top levels of a Merkle tree, a
 // single `Jive::compress` through the shim); the lane-private path of mont29.h is the throughput
 // path (4x the multiplications per instruction, but one lane needs ~2.6 ms / 8.6 ms for a
 // 255-bit / 381-bit compression).
@@ -21,13 +21,16 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include <type_traits>
+
 #include "field_consts_gen.h"
 #include "mont29.h"  // ANEMOI_ASM_MUL and the generated assembly (mont29_asm_gen.h)
 
 namespace anemoi {
 
-template <class F>
+template <class F, int LPR = 64>
 struct Coop29 {
+  static_assert(LPR == 64 || LPR == 16, "one element per wavefront, or one per 16-lane DPP row");
   using L = typename F::Coop;  // always the 29-bit layout: the systolic scan below sums a whole
                                // column (2 NL products) in one 64-bit lane accumulator
   static_assert(L::W == 29, "column sums of 2 NL limb products must fit 64 bits");
@@ -44,11 +47,13 @@ struct Coop29 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
   }
   __device__ static __forceinline__ uint32_t lane() { return threadIdx.x; }
-  __device__ static __forceinline__ uint32_t keep(uint32_t v) { return lane() < NL ? v : 0u; }
+  __device__ static __forceinline__ uint32_t limb() { return threadIdx.x & (LPR - 1); }       // j: which limb this lane holds
+  __device__ static __forceinline__ uint32_t row0() { return threadIdx.x & ~uint32_t(LPR - 1); }  // first lane of the element
+  __device__ static __forceinline__ uint32_t keep(uint32_t v) { return limb() < NL ? v : 0u; }
 
-  // per-lane copy of a field constant (limb `lane`, 0 beyond NL)
+  // per-lane copy of a field constant (limb j, 0 beyond NL)
   __device__ static __forceinline__ uint32_t konst(const uint32_t* __restrict__ k) {
-    return lane() < NL ? k[lane()] : 0u;
+    return limb() < NL ? k[limb()] : 0u;
   }
 
   // two carry passes: 64-bit column sums -> limbs < 2^29 + 2^7
@@ -67,7 +72,9 @@ struct Coop29 {
     return keep((r & MASK) + from_prev(r >> 29));
   }
 
-  // limbs < 2^30 -> limbs < 2^29 exactly (ballot carry look-ahead, see the header comment)
+  // limbs < 2^30 -> limbs < 2^29 exactly (ballot carry look-ahead, see the header comment).  With four elements
+  // per wavefront the one 64-bit add serves all four: lanes j >= NL of a row (at least two: NL <= 14) hold zero,
+  // so neither generate nor propagate, and no carry crosses into the next row.
   __device__ static __forceinline__ uint32_t norm_exact(uint32_t r) {
     r = carry32(r);  // now < 2^29 + 8: at most a single carry bit out of any limb
     const unsigned long long G = __ballot(r > MASK), P = __ballot(r == MASK);
@@ -77,18 +84,24 @@ struct Coop29 {
 
   // Montgomery product (limbs of a, b < 2^29 + 2^7): result < 2p when (a/p)(b/p) <= R'/p
   __device__ static __forceinline__ uint32_t mul(uint32_t a, uint32_t b, uint32_t pl) {
-    const uint32_t sh = lane() == 0 ? 29u : 63u;
+    const uint32_t sh = limb() == 0 ? 29u : 63u;
 #if ANEMOI_ASM_MUL
-    // the same scan as below, hand-scheduled (tools/gen_asm_mul.py gen_coop_mul: 10 issue slots per step
-    // instead of hipcc's 13)
-    return settle_columns(AsmCoop<F::kId>::mul(a, b, pl, sh));
+    // the same scan as below, hand-scheduled (tools/gen_asm_mul.py gen_coop_mul / gen_coop4_mul: 10 issue slots
+    // per step instead of hipcc's 13)
+    if constexpr (LPR == 64) return settle_columns(AsmCoop<F::kId>::mul(a, b, pl, sh));
+    else return settle_columns(AsmCoop4<F::kId>::mul(a, b, pl, sh, MASK));
 #endif
     uint64_t t = 0;
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-      const uint32_t ai = __builtin_amdgcn_readlane(a, i);
+    static_for_limbs<0>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      // a_i and the quotient digit: wave-uniform (v_readlane -> SGPR) with one element per wavefront, a DPP
+      // broadcast inside each row with four
+      uint32_t ai, t0;
+      if constexpr (LPR == 64) ai = __builtin_amdgcn_readlane(a, i);
+      else ai = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x150 + i /* row_newbcast:i */, 0xf, 0xf, false);
       t += (uint64_t)ai * b;
-      const uint32_t t0 = __builtin_amdgcn_readlane((uint32_t)t, 0);
+      if constexpr (LPR == 64) t0 = __builtin_amdgcn_readlane((uint32_t)t, 0);
+      else t0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)t, 0x150 /* row_newbcast:0 */, 0xf, 0xf, false);
       const uint32_t m = (t0 * L::kN0Inv) & MASK;
       t += (uint64_t)m * pl;
       // lane 0's column is now 0 mod 2^29 and retires: its upper bits are the carry into the next
@@ -96,8 +109,16 @@ struct Coop29 {
       // a per-lane shift amount replaces a mask.
       const uint64_t u = t >> sh;
       t = (((uint64_t)from_next((uint32_t)(t >> 32)) << 32) | from_next((uint32_t)t)) + u;
-    }
+    });
     return settle_columns(t);
+  }
+
+  template <int I, class Fn>
+  __device__ static __forceinline__ void static_for_limbs(Fn&& fn) {
+    if constexpr (I < NL) {
+      fn(std::integral_constant<int, I>{});
+      static_for_limbs<I + 1>(fn);
+    }
   }
 
   __device__ static __forceinline__ uint32_t add(uint32_t a, uint32_t b) { return carry32(a + b); }
@@ -119,29 +140,29 @@ struct Coop29 {
   __device__ static __forceinline__ uint32_t canonical(uint32_t x, uint32_t pl) {
     x = norm_exact(x);
     // borrow look-ahead for x - p: generate where x_j < p_j, propagate where equal
-    const unsigned long long G = __ballot(x < pl), P = __ballot(x == pl && lane() < NL);
+    const unsigned long long G = __ballot(x < pl), P = __ballot(x == pl && limb() < NL);
     const unsigned long long B = ((G << 1) + P) ^ P;           // borrow-in per limb
-    const bool below = (((G << 1) + P) >> NL) & 1;              // borrow out of the top limb: x < p
+    const bool below = (((G << 1) + P) >> (row0() + NL)) & 1;   // borrow out of this element's top limb: x < p
     const uint32_t d = (x - pl - (uint32_t)((B >> lane()) & 1)) & MASK;
     return below ? x : keep(d);
   }
 
   // ABI words (lane j < NABI holds 32-bit word j of x * 2^(32 NABI) mod p) -> internal limbs
   __device__ static __forceinline__ uint32_t words_to_limbs(uint32_t w) {
-    const int bit = 29 * (int)lane(), lo = bit >> 5, sh = bit & 31;
-    const uint32_t wl = __shfl(w, lo < NABI ? lo : 0), wh = __shfl(w, lo + 1 < NABI ? lo + 1 : 0);
+    const int bit = 29 * (int)limb(), lo = bit >> 5, sh = bit & 31, r0 = (int)row0();
+    const uint32_t wl = __shfl(w, r0 + (lo < NABI ? lo : 0)), wh = __shfl(w, r0 + (lo + 1 < NABI ? lo + 1 : 0));
     const uint32_t a = lo < NABI ? wl : 0u, b = lo + 1 < NABI ? wh : 0u;
     const uint32_t v = sh == 0 ? a : ((a >> sh) | (b << (32 - sh)));
     return keep(v & MASK);
   }
   __device__ static __forceinline__ uint32_t limbs_to_words(uint32_t l) {  // exact limbs, value < 2^(32 NABI)
-    const int bit = 32 * (int)lane(), i0 = bit / 29, off = bit - 29 * i0;
-    const uint32_t l0 = __shfl(l, i0 < 64 ? i0 : 0), l1 = __shfl(l, i0 + 1 < 64 ? i0 + 1 : 0),
-                   l2 = __shfl(l, i0 + 2 < 64 ? i0 + 2 : 0);
+    const int bit = 32 * (int)limb(), i0 = bit / 29, off = bit - 29 * i0, r0 = (int)row0();
+    const uint32_t l0 = __shfl(l, r0 + (i0 < LPR ? i0 : 0)), l1 = __shfl(l, r0 + (i0 + 1 < LPR ? i0 + 1 : 0)),
+                   l2 = __shfl(l, r0 + (i0 + 2 < LPR ? i0 + 2 : 0));
     uint32_t v = l0 >> off;
     v |= off == 0 ? (l1 << 29) : (l1 << (29 - off));
     if (58 - off < 32) v |= l2 << (58 - off);
-    return lane() < NABI ? v : 0u;
+    return limb() < NABI ? v : 0u;
   }
   __device__ static __forceinline__ uint32_t from_abi(uint32_t w, uint32_t pl) {
     return mul(words_to_limbs(w), konst(L::In), pl);

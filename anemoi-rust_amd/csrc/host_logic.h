@@ -97,23 +97,32 @@ inline ChunkPlan plan_chunks(size_t n, size_t quantum, size_t in_bytes_per_item,
   return {items, (n + items - 1) / items};
 }
 
-// Chunk plan of a RAGGED batch (message i = bytes [off[i], off[i+1]) of one blob): cut at message boundaries
-// so that a chunk holds at most `target_bytes` of message bytes (a single longer message is a chunk of its
-// own), its message count a multiple of `align` (one wavefront's worth of messages: a chunk boundary inside
-// a wavefront would leave idle lanes) whenever it has at least `align` messages, and at most `max_items`
-// messages (many empty messages must not make an unbounded offsets table).  Returns the first message of
-// every chunk plus n at the end; every chunk is non-empty.
+// Chunk plan of a RAGGED batch (message i = bytes [off[i], off[i+1]) of one blob), cut at message boundaries.
+// A chunk takes messages until it holds `target_bytes` AND `min_items` messages (a chunk with fewer messages than
+// half a wave of workgroups leaves the machine underfilled however many bytes it has: these kernels cost what
+// their wavefronts' longest messages cost), but never more than `max_bytes` (staging stays bounded; a single
+// longer message is a chunk of its own) nor more than `max_items` messages (many empty messages must not make
+// an unbounded offsets table).  Its message count is a multiple of `align` (one wavefront's worth of messages)
+// whenever it has at least `align`.  Returns the first message of every chunk plus n at the end; every chunk
+// is non-empty.
 inline std::vector<size_t> plan_ragged_chunks(const uint64_t* off, size_t n, size_t target_bytes, size_t align,
-                                              size_t max_items) {
+                                              size_t min_items, size_t max_items, size_t max_bytes) {
   std::vector<size_t> cuts;
   if (align == 0) align = 1;
   if (max_items < align) max_items = align;
+  if (min_items > max_items) min_items = max_items;
+  if (max_bytes < target_bytes) max_bytes = target_bytes;
   size_t first = 0;
   while (first < n) {
     cuts.push_back(first);
     size_t end = first;
-    while (end < n && end - first < max_items && off[end + 1] - off[first] <= target_bytes) end++;
-    if (end == first) end = first + 1;  // one message longer than the target
+    while (end < n && end - first < max_items) {
+      const uint64_t with = off[end + 1] - off[first];
+      if (with > max_bytes) break;
+      if (with > target_bytes && end - first >= min_items) break;
+      end++;
+    }
+    if (end == first) end = first + 1;  // one message longer than the cap
     size_t cnt = end - first;
     if (cnt >= align) cnt = cnt / align * align;
     first += cnt;

@@ -115,9 +115,10 @@ static void test_overlap_and_chunks() {
 static void test_ragged_chunks() {
   uint64_t seed = 12345;
   auto rnd = [&]() { return seed = seed * 6364136223846793005ull + 1442695040888963407ull, seed >> 33; };
-  for (int trial = 0; trial < 400; trial++) {
+  for (int trial = 0; trial < 600; trial++) {
     const size_t n = rnd() % 700;
     const size_t target = 1 + rnd() % 5000, align = trial % 3 == 0 ? 1 : 64, max_items = 64 + rnd() % 400;
+    const size_t min_items = rnd() % 200, max_bytes = target * (1 + rnd() % 8);
     std::vector<uint64_t> off(n + 1);
     off[0] = rnd() % 100;   // offsets need not start at 0
     for (size_t i = 0; i < n; i++) {
@@ -125,18 +126,24 @@ static void test_ragged_chunks() {
       const uint64_t len = kind == 0 ? 0 : kind == 1 ? rnd() % 20000 : rnd() % 200;
       off[i + 1] = off[i] + len;
     }
-    const std::vector<size_t> cuts = plan_ragged_chunks(off.data(), n, target, align, max_items);
+    const std::vector<size_t> cuts = plan_ragged_chunks(off.data(), n, target, align, min_items, max_items, max_bytes);
+    const size_t cap_items = max_items < align ? align : max_items;
+    const size_t want_items = min_items > cap_items ? cap_items : min_items;
     CHECK(!cuts.empty() && cuts.back() == n && (n == 0 ? cuts.size() == 1 : cuts.front() == 0));
     for (size_t c = 0; c + 1 < cuts.size(); c++) {
       const size_t a = cuts[c], b = cuts[c + 1];
       CHECK(a < b);                                              // non-empty, increasing
-      CHECK(b - a <= (max_items < align ? align : max_items));   // bounded offsets table
+      CHECK(b - a <= cap_items);                                 // bounded offsets table
       const uint64_t bytes = off[b] - off[a];
-      CHECK(bytes <= target || b - a == 1);                      // bounded staging, or one long message alone
+      CHECK(bytes <= max_bytes || b - a == 1);                   // bounded staging, or one long message alone
       if (b - a > align) CHECK((b - a) % align == 0);            // whole wavefronts
-      // greedy: the chunk could not have taken `align` more messages (unless it ran into max_items / the end)
-      if (b < n && b - a + align <= max_items && b - a >= align && b + align <= n)
-        CHECK(off[b + align] - off[a] > target);
+      // beyond the byte target only to reach the minimum message count
+      if (bytes > target && b - a > 1) CHECK(b - a <= want_items + align);
+      // greedy: a chunk that stopped early (not at the end, not at a cap) could not have taken `align` more messages
+      if (b + align <= n && b - a + align <= cap_items && b - a >= align) {
+        const uint64_t more = off[b + align] - off[a];
+        CHECK(more > max_bytes || (more > target && b - a + align > want_items));
+      }
     }
   }
 }

@@ -209,3 +209,153 @@ def test_the_interpreter_notices_an_overflow():
     assert run(lines[:3], outs, [], [M32]) == [M32]
     with pytest.raises(Overflow):
         run(lines, outs, [], [M32])
+
+
+# ---- the wave-cooperative products (AsmCoop: one element per wavefront; AsmCoop4: one per 16-lane DPP row) ------------
+# A 64-lane interpreter of the handful of instructions those statements use, DPP controls included
+# (row_newbcast:i = lane i of the own 16-lane row; row_shl:1 with bound_ctrl = lane + 1 of the own row, 0 beyond it),
+# with the same overflow detection.  What cannot be modelled here is timing (the s_nop hazard slots): that is what the
+# GPU parity test with both kernels forced is for.
+
+def parse_coop(struct):
+    text = open(HDR).read()
+    out = {}
+    for m in re.finditer(r"template <> struct %s<(\d+)> \{(.*?)\n\};" % struct, text, re.S):
+        fn = re.search(r"asm volatile\((.*?)\);", m.group(2), re.S).group(1)
+        out[int(m.group(1))] = re.findall(r'"([^"]+?)\\n\\t"', fn)
+    return out
+
+
+def run_coop(lines, a, b, pl, sh, mask=None):
+    """a, b, pl, sh: 64-entry lists (per lane); returns the 64 column sums t = (hi << 32) | lo"""
+    L = 64
+    v, sreg, vcc = {}, {}, [0] * L
+    opnd = {"%2": a, "%3": b, "%4": pl, "%5": sh, "%6": [mask] * L if mask is not None else None}
+    outv = {}
+
+    def vec(tok):
+        tok = tok.strip()
+        if tok in opnd:
+            return list(opnd[tok])
+        if tok in ("%0", "%1"):
+            return list(outv[tok])
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            lo, hi = v["v%s" % m.group(1)], v["v%d" % (int(m.group(1)) + 1)]
+            return [l | (h << 32) for l, h in zip(lo, hi)]
+        if tok.startswith("v"):
+            return list(v[tok])
+        if tok.startswith("s"):
+            return [sreg[tok]] * L
+        return [int(tok, 0) & M64] * L
+
+    def put(tok, vals):
+        tok = tok.strip()
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            v["v%s" % m.group(1)] = [x & M32 for x in vals]
+            v["v%d" % (int(m.group(1)) + 1)] = [(x >> 32) & M32 for x in vals]
+        elif tok in ("%0", "%1"):
+            outv[tok] = [x & M32 for x in vals]
+        else:
+            v[tok] = [x & M32 for x in vals]
+
+    def dpp(vals, ctrl):
+        m = re.search(r"row_newbcast:(\d+)", ctrl)
+        if m:
+            return [vals[(l & ~15) + int(m.group(1))] for l in range(L)]
+        assert "row_shl:1" in ctrl and "bound_ctrl:1" in ctrl, ctrl
+        return [vals[l + 1] if (l & 15) != 15 else 0 for l in range(L)]
+
+    for ln in lines:
+        op, _, rest = ln.partition(" ")
+        ctrl = ""
+        m = re.search(r"\s(row_[a-z_]+:.*)$", rest)
+        if m:
+            ctrl, rest = m.group(1), rest[:m.start()]
+        args = [x.strip() for x in re.split(r",\s*(?![^\[]*\])", rest)] if rest.strip() else []
+        if op == "s_nop":
+            continue
+        if op == "s_mov_b32":
+            sreg[args[0]] = int(args[1], 0)
+        elif op == "v_readlane_b32":
+            sreg[args[0]] = vec(args[1])[int(args[2])]
+        elif op == "s_mul_i32":
+            sreg[args[0]] = (sreg[args[1]] * int(args[2], 0)) & M32
+        elif op == "s_sub_i32":
+            sreg[args[0]] = (int(args[1], 0) - sreg[args[2]]) & M32
+        elif op == "s_and_b32":
+            sreg[args[0]] = sreg[args[1]] & int(args[2], 0)
+        elif op in ("v_mov_b32", "v_mov_b32_dpp"):
+            src = vec(args[1])
+            put(args[0], dpp(src, ctrl) if ctrl else src)
+        elif op == "v_mad_u64_u32":
+            s0, s1, s2 = vec(args[2]), vec(args[3]), vec(args[4])
+            val = [x * y + z for x, y, z in zip(s0, s1, s2)]
+            if max(val) > M64:
+                raise Overflow(ln)
+            put(args[0], val)
+        elif op == "v_sub_u32":
+            put(args[0], [(x - y) & M32 for x, y in zip(vec(args[1]), vec(args[2]))])
+        elif op == "v_mul_lo_u32":
+            put(args[0], [(x * y) & M32 for x, y in zip(vec(args[1]), vec(args[2]))])
+        elif op == "v_and_b32_dpp":
+            put(args[0], [x & y for x, y in zip(dpp(vec(args[1]), ctrl), vec(args[2]))])
+        elif op == "v_lshrrev_b64":
+            put(args[0], [x >> (s & 63) for s, x in zip(vec(args[1]), vec(args[2]))])
+        elif op == "v_add_co_u32_dpp":
+            s = [x + y for x, y in zip(dpp(vec(args[2]), ctrl), vec(args[3]))]
+            vcc = [x >> 32 for x in s]
+            put(args[0], s)
+        elif op == "v_addc_co_u32_dpp":
+            s = [x + y + c for x, y, c in zip(dpp(vec(args[2]), ctrl), vec(args[3]), vcc)]
+            if max(s) > M32:
+                raise Overflow(ln)     # the column sums are dimensioned to stay below 2^63
+            put(args[0], s)
+        else:
+            raise AssertionError("instruction not modelled: " + ln)
+    return [lo | (hi << 32) for lo, hi in zip(outv["%0"], outv["%1"])]
+
+
+@pytest.mark.parametrize("struct,rows", [("AsmCoop", 1), ("AsmCoop4", 4)])
+@pytest.mark.parametrize("fid", range(7))
+def test_cooperative_products_on_adversarial_limbs(moduli, struct, rows, fid):
+    """Each row's column sums must add up to a b / R' mod p (value level), stay below 2^63 (the per-lane shift by 63
+    relies on it) and -- with four elements per wavefront -- no row may see anything of its neighbours."""
+    W, p = 29, moduli[fid]
+    nl = -(-(p.bit_length() + 6) // W)
+    lines = parse_coop(struct)[fid]
+    Rinv = pow(1 << (W * nl), -1, p)
+    full = (1 << W) - 1 + (1 << 7)          # limbs as the previous product's settle_columns leaves them: < 2^29 + 2^7
+    rng = random.Random(1000 + fid)
+    H = (1 << (W * nl)) // p
+    import math
+    A = min(math.isqrt(H), 1 << 12)
+    lpr = 64 // rows
+
+    def operands():
+        kind = rng.randrange(4)
+        if kind == 0:
+            return [full] * (nl - 1) + [min(full, (A * p) >> (W * (nl - 1)))]
+        if kind == 1:
+            return limbs_of(rng.randrange(A * p), W, nl)
+        if kind == 2:
+            return limbs_of(p - 1, W, nl)
+        return [0] * nl
+    pl_limbs = limbs_of(p, W, nl)
+    for trial in range(6):
+        a_rows = [operands() for _ in range(rows)]
+        b_rows = [operands() for _ in range(rows)]
+        lane = lambda vals_rows: [(vals_rows[l // lpr][l % lpr] if l // lpr < rows and l % lpr < nl else 0) for l in range(64)]
+        a, b = lane(a_rows), lane(b_rows)
+        pl = lane([pl_limbs] * rows)
+        sh = [29 if l % lpr == 0 else 63 for l in range(64)]
+        t = run_coop(lines, a, b, pl, sh, mask=(1 << W) - 1 if struct == "AsmCoop4" else None)
+        for r in range(rows):
+            cols = t[r * lpr:r * lpr + nl]
+            assert all(c < (1 << 63) for c in cols)
+            got = sum(c << (W * j) for j, c in enumerate(cols))
+            av, bv = value(a_rows[r], W), value(b_rows[r], W)
+            assert got % p == av * bv * Rinv % p, (struct, fid, trial, r)
+            assert got < 2 * p + (av * bv >> (W * nl))      # (a b + m p) / R' with m < R'
+            assert all(c == 0 for c in t[r * lpr + nl:(r + 1) * lpr])   # lanes beyond the element stay zero

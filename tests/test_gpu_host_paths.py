@@ -64,7 +64,7 @@ def test_ragged_sponge_through_many_chunks(A, oracle, staging):
             lens[pos] = ln
         msgs = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for n in lens]
         whole = inst.hash_ragged(msgs)                      # one chunk (default target)
-        with env(ANEMOI_CHUNK_TARGET_BYTES=4096, ANEMOI_HOST_STAGING=staging):
+        with env(ANEMOI_CHUNK_TARGET_BYTES=4096, ANEMOI_TEST_QUANTUM=128, ANEMOI_HOST_STAGING=staging):
             got = inst.hash_ragged(msgs)
             with env(ANEMOI_VIRTUAL_DEVICES=3):
                 many = A.Anemoi(field, width, device=A.ALL_DEVICES).hash_ragged(msgs)
@@ -72,7 +72,7 @@ def test_ragged_sponge_through_many_chunks(A, oracle, staging):
         for i in list(range(0, 700, 7)) + [5, 64, 65, 333, 699]:
             assert (got[i] == oracle.hash_bytes(fid, width, msgs[i])).all(), (field, width, i, lens[i])
         # all-empty batch and a batch of one long message
-        with env(ANEMOI_CHUNK_TARGET_BYTES=4096, ANEMOI_HOST_STAGING=staging):
+        with env(ANEMOI_CHUNK_TARGET_BYTES=4096, ANEMOI_TEST_QUANTUM=128, ANEMOI_HOST_STAGING=staging):
             assert (inst.hash_ragged([b""] * 200) == 0).all()
             one = inst.hash_ragged([msgs[333]])
         assert (one[0] == whole[333]).all()

@@ -367,9 +367,10 @@ def test_cfg5_jubjub_merkle_depth14(A, oracle, params):
 
 
 def test_cooperative_and_lane_private_paths_agree(oracle, params):
-    """Jive 2-1 has two kernels: wave-cooperative (one item per wavefront, batches <= 2048) and
-    lane-private (one item per lane).  ANEMOI_COOP_MAX forces each for every size; both must match the
-    oracle bit for bit on all 7 fields, ragged sizes and edge states."""
+    """Jive 2-1 has three kernels: wave-cooperative with one item per wavefront (small batches), row-cooperative
+    with four items per wavefront (one per 16-lane DPP row; medium batches) and lane-private (one item per lane).
+    ANEMOI_COOP_MAX / ANEMOI_COOP4_MAX force each for every size; all must match the oracle bit for bit on all 7
+    fields, ragged sizes (partly filled wavefronts and rows) and edge states."""
     import subprocess, sys, os
     from conftest import ROOT
     code = r'''
@@ -383,7 +384,7 @@ params = json.load(open(os.path.join(ROOT, "tests", "golden", "params.json")))
 for fid, field in enumerate(A.FIELD_IDS):
     p, L = int(params[field]["modulus"]), params[field]["u64_limbs"]
     rng = random.Random(fid)
-    for n in (1, 2, 65, 300):
+    for n in (1, 2, 3, 7, 65, 300):
         st = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(2 * n)]).reshape(n, 2, L)
         st[0] = 0
         if n > 1:
@@ -394,10 +395,10 @@ for fid, field in enumerate(A.FIELD_IDS):
     assert (A.Anemoi(field, 2).merkle_root(leaves, 6) == oracle.merkle_root(fid, leaves, 6)).all()
 print("ok")
 '''.replace("ROOT", repr(ROOT))
-    for coop_max in ("0", "1000000000"):
-        env = dict(os.environ, ANEMOI_COOP_MAX=coop_max)
+    for coop_max, coop4_max in (("0", "0"), ("1000000000", "0"), ("0", "1000000000")):
+        env = dict(os.environ, ANEMOI_COOP_MAX=coop_max, ANEMOI_COOP4_MAX=coop4_max)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-        assert out.returncode == 0 and "ok" in out.stdout, (coop_max, out.stdout[-1500:], out.stderr[-1500:])
+        assert out.returncode == 0 and "ok" in out.stdout, (coop_max, coop4_max, out.stdout[-1500:], out.stderr[-1500:])
 
 
 def test_concurrent_callers(A, oracle, params):

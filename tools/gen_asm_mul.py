@@ -322,6 +322,58 @@ def gen_coop_mul(nl, n0inv, W=29):
     return out, clob
 
 
+def gen_coop4_mul(nl, n0inv, W=29):
+    """Row-cooperative Montgomery product: FOUR elements per wavefront, one per 16-lane DPP row (lane 16 r + j holds
+    limb j of element r, j < nl <= 14; lanes j >= nl hold zero) -- the same operand scan as gen_coop_mul(), but nothing
+    in it may be wave-uniform any more: a_i and the quotient digit differ from row to row, so
+        a_i   is broadcast inside each row by DPP (v_mov_b32_dpp row_newbcast:i) instead of v_readlane -> SGPR,
+        m     = -(T_j=0.lo) / p mod 2^W  is computed on the VALU in every lane and lane 0's value broadcast and masked
+                by ONE VOP2-DPP instruction (v_and_b32_dpp m, x, MASK row_newbcast:0) instead of readlane + SALU.
+    Operands: %0 = t.lo (out), %1 = t.hi (out), %2 = a, %3 = b, %4 = p limb of this lane, %5 = per-lane shift amount
+    (W in lane j = 0 of each row, 63 elsewhere), %6 = MASK (a VGPR: src1 of a VOP2).  Per step i:
+        T += a_i * b
+        x  = T.lo * n0inv                    (v_sub_u32 x, 0, T.lo when p = 1 mod 2^W)
+        m  = bcast_row(x, 0) & MASK          the next a_i is broadcast in the wait states in front of this DPP read
+        T += m * p_lane
+        U  = T >> shift                      lane 0 of a row: the retired column's carry; other lanes: 0 (T < 2^63)
+        T  = T_{lane+1} + U                  v_add_co_u32 / v_addc_co_u32 with DPP row_shl:1 on src0
+    10 issue slots per step like the one-element scan (whose quotient digit runs on the scalar ALU).  Hazard slots
+    by hand: VALU-written VGPR -> DPP source needs 2 wait states."""
+    MASK = (1 << W) - 1
+    T, U, X, M, A0 = COOP_VBASE, COOP_VBASE + 2, COOP_VBASE + 4, COOP_VBASE + 5, COOP_VBASE + 6
+    TT, UU = "v[%d:%d]" % (T, T + 1), "v[%d:%d]" % (U, U + 1)
+    SN = "s%d" % COOP_SBASE
+    shl = "row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    bc = lambda i: "row_newbcast:%d row_mask:0xf bank_mask:0xf" % i
+    A = lambda i: "v%d" % (A0 + (i & 1))
+    out = ["s_nop 1"]   # whatever VALU wrote `a` last: settled before the first DPP read
+    if n0inv != MASK:
+        out.append("s_mov_b32 %s, 0x%x" % (SN, n0inv))
+    out.append("v_mov_b32_dpp %s, %%2 %s" % (A(0), bc(0)))
+    for i in range(nl):
+        out.append("v_mad_u64_u32 %s, vcc, %s, %%3, %s" % (TT, A(i), TT if i else "0"))
+        if n0inv == MASK:
+            out.append("v_sub_u32 v%d, 0, v%d" % (X, T))
+        else:
+            out.append("v_mul_lo_u32 v%d, v%d, %s" % (X, T, SN))
+        if i + 1 < nl:
+            out.append("v_mov_b32_dpp %s, %%2 %s" % (A(i + 1), bc(i + 1)))   # fills one of the two wait states
+            out.append("s_nop 0")
+        else:
+            out.append("s_nop 1")
+        out.append("v_and_b32_dpp v%d, v%d, %%6 %s" % (M, X, bc(0)))
+        out.append("v_mad_u64_u32 %s, vcc, v%d, %%4, %s" % (TT, M, TT))
+        out.append("v_lshrrev_b64 %s, %%5, %s" % (UU, TT))
+        out.append("s_nop 0")
+        out.append("v_add_co_u32_dpp v%d, vcc, v%d, v%d %s" % (T, T, U, shl))
+        out.append("v_addc_co_u32_dpp v%d, vcc, v%d, v%d, vcc %s" % (T + 1, T + 1, U + 1, shl))
+    out.append("v_mov_b32 %%0, v%d" % T)
+    out.append("v_mov_b32 %%1, v%d" % (T + 1))
+    out.append("s_nop 1")  # the caller's next instructions read the results through DPP
+    clob = ["v%d" % r for r in range(COOP_VBASE, A0 + 2)] + ([SN] if n0inv != MASK else []) + ["vcc"]
+    return out, clob
+
+
 def coop_qp_params(p, W=29):
     """Quotient-pipelined form of the cooperative product (Orup 1995, delay d = 1), radix 2^W:
     Mt = (-p^-1 mod 2^2W) p  (= -1 mod 2^2W),  Mq = (Mt + 1) / 2^2W,  n = number of W-bit digits with 4 Mt < 2^(W n)
@@ -431,6 +483,21 @@ def main():
         h.append("  __device__ static __forceinline__ uint64_t mul(uint32_t a, uint32_t b, uint32_t pl, uint32_t sh) {")
         h.append("    uint32_t lo, hi;")
         h.append(emit("coop", co, ['"=&v"(lo)', '"=&v"(hi)'], ['"v"(a)', '"v"(b)', '"v"(pl)', '"v"(sh)'], co_clob))
+        h.append("    return ((uint64_t)hi << 32) | lo;")
+        h.append("  }")
+        h.append("};")
+    h.append("// Row-cooperative product: four elements per wavefront, one per 16-lane DPP row -- see gen_coop4_mul().")
+    h.append("template <int FIELD> struct AsmCoop4;")
+    for fid, name in enumerate(FIELD_IDS):
+        p = int(params[name]["modulus"])
+        nl, pl, n0 = field_consts(p, 29)
+        co, co_clob = gen_coop4_mul(nl, n0)
+        h.append("// %s: %d steps, %d instructions" % (name, nl, len(co)))
+        h.append("template <> struct AsmCoop4<%d> {" % fid)
+        h.append("  __device__ static __forceinline__ uint64_t mul(uint32_t a, uint32_t b, uint32_t pl, uint32_t sh, uint32_t mask) {")
+        h.append("    uint32_t lo, hi;")
+        h.append(emit("coop4", co, ['"=&v"(lo)', '"=&v"(hi)'],
+                      ['"v"(a)', '"v"(b)', '"v"(pl)', '"v"(sh)', '"v"(mask)'], co_clob))
         h.append("    return ((uint64_t)hi << 32) | lo;")
         h.append("  }")
         h.append("};")

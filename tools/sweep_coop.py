@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Which Jive 2-1 kernel for which batch size?  Times the three kernels -- wave-cooperative (one item per wavefront),
+row-cooperative (four items per wavefront, one per 16-lane DPP row) and lane-private (one item per lane) -- on
+device-resident batches of 1 .. 65 536 items in ONE process (the selection knobs ANEMOI_COOP_MAX / ANEMOI_COOP4_MAX are
+read at every call), checks that all three agree bit for bit, and prints the per-size table plus the Merkle-tree time
+each cut-off policy would give (a depth-d tree is one launch per level: 2^(d-1), .., 2, 1 items).
+
+    python tools/sweep_coop.py [field ...]            (default: jubjub bls12_381)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "anemoi-rust_amd"))
+import numpy as np
+import torch
+import anemoi_amd as A
+from anemoi_amd import synth
+
+fields = [a for a in sys.argv[1:]] or ["jubjub", "bls12_381"]
+dev = torch.device("cuda", 0)
+s = torch.cuda.current_stream()
+BIG = "1000000000"
+MODES = {"coop1": (BIG, "0"), "coop4": ("0", BIG), "lane": ("0", "0")}
+
+
+def timed(fid, d_in, d_out, n, reps=5):
+    ts = []
+    for _ in range(reps + 1):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        assert A.lib.anemoi_jive_compress_k_dev(fid, 2, 2, d_in.data_ptr(), d_out.data_ptr(), n, s.cuda_stream) == 0
+        b.record(s)
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return sorted(ts[1:])[len(ts[1:]) // 2]
+
+
+for field in fields:
+    fid, L = A.field_id(field), synth.limbs_of(field)
+    sizes = [1 << k for k in range(0, 17)]
+    st = synth.states(field, 2, 0xC0, 0, sizes[-1])
+    d_in = torch.from_numpy(st.view(np.int64).reshape(-1)).to(dev)
+    table = {}
+    print("%s: kernel time in ms per batch size (median of 5, device-resident)" % field)
+    print("%8s %9s %9s %9s   best" % ("items", "coop1", "coop4", "lane"))
+    for n in sizes:
+        row, ref = {}, None
+        for mode, (c1, c4) in MODES.items():
+            if mode == "coop1" and n > 16384:
+                continue     # one wavefront per item: 65 536 wavefronts of a latency kernel are pointless
+            os.environ["ANEMOI_COOP_MAX"], os.environ["ANEMOI_COOP4_MAX"] = c1, c4
+            d_out = torch.zeros(n * L, dtype=torch.int64, device=dev)
+            row[mode] = timed(fid, d_in, d_out, n)
+            got = d_out.cpu()
+            if ref is None:
+                ref = got
+            assert torch.equal(ref, got), (field, n, mode)
+        table[n] = row
+        best = min(row, key=row.get)
+        print("%8d %9s %9.3f %9.3f   %s" % (n, "%9.3f" % row["coop1"] if "coop1" in row else "-", row["coop4"], row["lane"], best))
+    os.environ.pop("ANEMOI_COOP_MAX", None)
+    os.environ.pop("ANEMOI_COOP4_MAX", None)
+
+    def tree_ms(depth, c1max, c4max):
+        t = 0.0
+        for l in range(depth):
+            n = 1 << (depth - 1 - l)
+            if n > sizes[-1]:
+                continue     # levels above the sweep are lane-private in every policy
+            mode = "coop1" if n <= c1max else ("coop4" if n <= c4max else "lane")
+            t += table[n][mode]
+        return t
+
+    depth = 17   # levels of 65 536 .. 1 items: the part of any deeper tree the choice affects
+    print("  levels of <= 65 536 items of a tree (17 launches), by cut-off policy (coop1 up to / coop4 up to):")
+    for c1max in (0, 256, 512, 1024, 2048):
+        for c4max in (0, 2048, 4096, 8192, 16384, 32768):
+            if c4max and c4max <= c1max:
+                continue
+            print("    coop1 <= %5d, coop4 <= %5d: %7.2f ms" % (c1max, c4max, tree_ms(depth, c1max, c4max)))
