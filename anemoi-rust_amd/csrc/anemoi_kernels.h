@@ -761,30 +761,6 @@ enum KernelKind { kKindPermutation = 0, kKindJive = 1, kKindSponge = 2, kKindCon
 
 const FieldOps* field_ops(int field);  // capi.hip
 
-// Launches that do not fill the machine (fewer workgroups than the CUs can hold at once: config 3's 2 048
-// wavefronts, the middle levels of a Merkle tree) run ONE long wavefront per workgroup from start to end, so the
-// time of the launch is the time of the fullest SIMD -- and the dispatcher does not spread workgroups evenly over
-// the CUs by itself.  Requesting just enough dynamic LDS that no CU can hold more than ceil(workgroups / CUs)
-// workgroups forces the even spread.  ANEMOI_BALANCE_LDS=0 switches it off (A/B; read at every call).
-inline size_t balanced_lds(size_t need, size_t workgroups, size_t natural_per_cu) {
-  if (const char* e = getenv("ANEMOI_BALANCE_LDS"))
-    if (e[0] == '0') return need;
-  static int cus_of[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return need;
-  if (!cus_of[dev]) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus_of[dev] = n;
-  }
-  const size_t cus = size_t(cus_of[dev]), k = (workgroups + cus - 1) / cus;   // workgroups per CU when spread evenly
-  if (k == 0 || k >= natural_per_cu) return need;
-  constexpr size_t kLdsPerCu = 160 * 1024, kGranule = 2048;
-  size_t lds = kLdsPerCu / (k + 1) / kGranule * kGranule + kGranule;   // smallest granule multiple that k + 1 of do not fit
-  if (lds > 65536) lds = 65536;                                         // the default per-workgroup limit
-  return lds > need ? lds : need;
-}
-
 inline unsigned grid_for(size_t n) { return unsigned((n + kBlock - 1) / kBlock); }
 inline unsigned pair_grid(size_t n) { return unsigned((n + kBlock / 2 - 1) / (kBlock / 2)); }  // 32 states per workgroup
 
@@ -864,25 +840,19 @@ struct Launch {
       k_jive2_coop<FIELD, 16><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
-    constexpr size_t kNat = A::NL >= 13 ? 12 : 16;   // resident wavefronts per CU these kernels are built for
     if (width == 2)
-      k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, balanced_lds(lds_bytes<A, WIN, 2>(), grid_for(n), kNat), s>>>(
-          (const uint4*)in, (uint4*)out, n, pc);
+      k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     else if (k == 2)
-      k_jive_pair<FIELD, 2><<<pair_grid(n), kBlock, balanced_lds(lds_bytes<A, WIN, 2>(), pair_grid(n), kNat), s>>>(
-          (const uint4*)in, (uint4*)out, n, pc);
+      k_jive_pair<FIELD, 2><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     else
-      k_jive_pair<FIELD, 4><<<pair_grid(n), kBlock, balanced_lds(lds_bytes<A, WIN, 2>(), pair_grid(n), kNat), s>>>(
-          (const uint4*)in, (uint4*)out, n, pc);
+      k_jive_pair<FIELD, 4><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     return hipGetLastError();
   }
 
   static hipError_t sponge_seg(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
                                SpongeSeg seg, hipStream_t s) {
     if (!n) return hipSuccess;
-    constexpr size_t kNat = A::NL >= 13 ? 12 : 16;
-    const size_t l = balanced_lds(lds_bytes<A, WIN, 1>(), grid_for(n), kNat);
-    const size_t lp = balanced_lds(lds_bytes<A, WIN, 2>(), pair_grid(n), kNat);
+    const size_t l = lds_bytes<A, WIN, 1>(), lp = lds_bytes<A, WIN, 2>();
     if (width == 2 && bytes)
       k_sponge<FIELD, 2, true><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc, seg);
     else if (width == 2)
