@@ -257,13 +257,39 @@ __device__ __forceinline__ void sbox_layer(typename A::Fe (&st)[W], const PermCo
   if (W == 4) flystel<F, A, WIN, USEX>(st[1], st[3], pc, tab);
 }
 
+// Two wavefronts that share a SIMD do not share it fairly: the arbiter prefers one of them (it runs at the lone-wave
+// rate, one instruction per ~6.5 cycles, the other gets the remaining slots), so in a launch with two resident
+// wavefronts per SIMD doing equal work -- config 3: 2 048 wavefronts on 1 024 SIMDs -- the preferred one finishes after
+// 0.73 of the time and its partner then runs ALONE at 61 % of the SIMD's issue rate: SQ_WAVE_CYCLES shows an average
+// residency of 0.79 and the launch is ~12 % slower than two fair halves would be (profiles/r03/pmc_configs.json).
+// Alternating the wave priority round by round, in opposite phase for even and odd wave slots of a SIMD, makes the
+// two take turns and finish together.  With 3-4 resident wavefronts (the full batches) it changes nothing.
+#ifndef ANEMOI_ALT_PRIO
+#define ANEMOI_ALT_PRIO 1
+#endif
+__device__ __forceinline__ uint32_t wave_slot() {
+#if ANEMOI_ALT_PRIO
+  return __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u;   // HW_ID.wave_id[3:0]: the slot on its SIMD
+#else
+  return 0;
+#endif
+}
+__device__ __forceinline__ void alternate_priority(int round, uint32_t slot) {
+#if ANEMOI_ALT_PRIO
+  if ((uint32_t(round) + slot) & 1u) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // Full permutation (src/traits.rs:370-378)
 template <class F, class A, int W, int WIN, bool USEX = true>
 __device__ __forceinline__ void permutation(typename A::Fe (&st)[W], const PermConsts& pc, const LdsTable<A>& tab) {
   constexpr int C = W / 2;
   constexpr int R = W == 2 ? F::kRounds21 : F::kRounds43;
+  const uint32_t slot = wave_slot();
 #pragma nounroll
   for (int r = 0; r < R; r++) {
+    alternate_priority(r, slot);
     static_for<0, C>([&](auto i) {
       add_global<A>(st[i], pc.ark_c + (r * C + i) * A::NL);
       add_global<A>(st[C + i], pc.ark_d + (r * C + i) * A::NL);
@@ -336,8 +362,10 @@ __device__ __forceinline__ void permutation_pair(typename A::Fe& x, typename A::
                                                  const LdsTable<A>& tab) {
   constexpr int R = F::kRounds43;
   const int col = odd ? 1 : 0;
+  const uint32_t slot = wave_slot();
 #pragma nounroll
   for (int r = 0; r < R; r++) {
+    alternate_priority(r, slot);
     add_global<A>(x, pc.ark_c + (r * 2 + col) * A::NL);
     add_global<A>(y, pc.ark_d + (r * 2 + col) * A::NL);
     mds_pair<F, A>(x, y, odd);

@@ -6,7 +6,7 @@
 # then tools/summarize_profiles.py turns them into the files kept under profiles/rNN/.
 #   tools/collect_profiles.sh <tag>
 set -o pipefail
-tag="${1:-r02}"
+tag="${1:-r03}"
 out="gpurun_out/prof_${tag}"
 mkdir -p "$out"
 export TMPDIR=/tmp
