@@ -585,9 +585,9 @@ ANEMOI_KERNEL void k_merkle_climb(const uint4* __restrict__ leaves, const uint64
       st[1].l[i] = right ? cur.l[i] : sib.l[i];
     }
     A::add(sum, cur, sib);
-    // plain window here (USEX = false): with cur, sib and the feed-forward sum live across the permutation the
-    // two extra digits would push this kernel past 168 VGPRs (182 / 138: one wave per SIMD less)
-    permutation<F, A, 2, WIN, false>(st, pc, tab);
+    // (round 2 ran the plain window here: with two 13-limb constants hoisted across the loop the extra digits
+    // pushed this kernel to 182 VGPRs; since the constants are pinned next to their use it fits with the digits)
+    permutation<F, A, 2, WIN>(st, pc, tab);
     A::add(cur, st[0], st[1]);
     A::add(cur, cur, sum);
     if (A::kLoose) A::settle(cur);

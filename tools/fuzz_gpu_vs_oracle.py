@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off differential fuzz: many random and structured states per field through the GPU kernels
-(lane-private and wave-cooperative Jive 2-1, Jive 4-3, permutation) against the C oracle.
+(lane-private, row-cooperative and wave-cooperative Jive 2-1, Jive 4-3, permutation) against the C oracle.
 Structured states stress carry patterns: limbs of all ones, values next to p and to 2^k, sparse values.
     python tools/fuzz_gpu_vs_oracle.py [items_per_field] [seed]"""
 import os
@@ -15,7 +15,7 @@ import numpy as np
 import orc
 import anemoi_amd as A
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000   # > 8192: the lane-private kernel
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 params = json.load(open(os.path.join(ROOT, "tests", "golden", "params.json")))
 oracle = orc.Oracle()
@@ -52,11 +52,13 @@ for fid, field in enumerate(A.FIELD_IDS):
         got = inst.compress_batch(st)
         ok = (got == exp).all()
         msg = "%-16s W=%d compress %6d items: %s" % (field, width, cnt, "ok" if ok else "MISMATCH")
-        if width == 2:  # force the other kernel too on a slice
-            small = st[:1500]
-            ok2 = (inst.compress_batch(small) == exp[:1500]).all()  # <= 2048 -> cooperative kernel
-            msg += "  coop(1500): %s" % ("ok" if ok2 else "MISMATCH")
-            ok = ok and ok2
+        if width == 2:  # the latency kernels on slices (the selection knobs are read at every call)
+            ok2 = (inst.compress_batch(st[:3001]) == exp[:3001]).all()  # <= 8192 -> row-cooperative kernel, 4 items per wavefront
+            os.environ["ANEMOI_COOP_MAX"] = "1000000"
+            ok4 = (inst.compress_batch(st[:700]) == exp[:700]).all()    # forced: one item per wavefront
+            del os.environ["ANEMOI_COOP_MAX"]
+            msg += "  row-coop(3001): %s  wave-coop(700): %s" % ("ok" if ok2 else "MISMATCH", "ok" if ok4 else "MISMATCH")
+            ok = ok and ok2 and ok4
         pg = inst.permutation_batch(st[:256])
         ok3 = all((pg[i] == oracle.permutation(fid, width, st[i])).all() for i in range(0, 256, 5))
         msg += "  permutation: %s" % ("ok" if ok3 else "MISMATCH")
