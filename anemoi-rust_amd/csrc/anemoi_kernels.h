@@ -619,6 +619,53 @@ inline size_t coop4_max_items(int) {
   if (const char* e = getenv("ANEMOI_COOP4_MAX")) return size_t(strtoull(e, nullptr, 10));
   return 8192;
 }
+// Anemoi-4-3: batches up to this many states take the row-cooperative kernel k_jive4_coop (two states per wavefront),
+// larger ones the lane-pair kernel; ANEMOI_COOP43_MAX overrides (0 = never)
+// (sweep in profiles/r03/coop_kernel_sweep.txt: BN-254 1.17 vs 1.64 ms at 2 048 states, 1.68 vs 1.66 at 4 096;
+// BLS12-381 3.35 vs 4.84 ms at 4 096, 5.95 vs 4.85 at 8 192)
+inline size_t coop43_max_items(int limbs29) {
+  if (const char* e = getenv("ANEMOI_COOP43_MAX")) return size_t(strtoull(e, nullptr, 10));
+  return limbs29 >= 14 ? 4096 : 2048;
+}
+
+// Flystel S-box (src/traits.rs:326-358) on the cooperative arithmetic: x -= g y^2 ; y -= x^(1/alpha) ; x += g y^2 + delta,
+// the exponentiation by a sliding window of F::kCoopWin bits over odd powers held in LDS (one word per lane and entry)
+template <class F, class C>
+__device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, uint32_t pl, uint32_t kpl, uint32_t delta,
+                                             uint32_t* tab, const PermConsts& pc) {
+  constexpr int E = 1 << (F::kCoopWin - 1);
+  const uint32_t lane = threadIdx.x;
+  uint32_t t = C::mul(y, y, pl);
+  x = C::sub(x, C::mul_g(t, pl), kpl);
+  {
+    const uint32_t x2 = C::mul(x, x, pl);
+    uint32_t pw = x;
+    tab[lane] = pw;
+#pragma nounroll
+    for (int i = 1; i < E; i++) {
+      pw = C::mul(pw, x2, pl);
+      tab[i * kBlock + lane] = pw;
+    }
+    uint32_t acc = tab[pc.first5 * kBlock + lane], tmp = acc;
+#pragma nounroll
+    for (int s = 0; s < pc.steps5; s++) {
+      const uint32_t word = pc.sched5[s];
+      const int nsq = word & 0xff, idx = word >> 8;
+      if (idx == 253) {  // leading-run doubling, see sliding_window() in tools/gen_params.py
+        tmp = acc;
+        continue;
+      }
+#pragma nounroll
+      for (int q = 0; q < nsq; q++) acc = C::mul(acc, acc, pl);
+      if (idx == 254) acc = C::mul(acc, tmp, pl);
+      else if (idx != 255) acc = C::mul(acc, tab[idx * kBlock + lane], pl);
+    }
+    t = acc;
+  }
+  y = C::sub(y, t, kpl);
+  t = C::mul(y, y, pl);
+  x = C::add(C::add(x, C::mul_g(t, pl)), delta);
+}
 
 template <int FIELD, int LPR>
 __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
@@ -650,43 +697,84 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
       x = C::settle(x, pl);
       y = C::settle(y, pl);
       if (r == R) break;  // permutation = R rounds + a final mds_layer (src/traits.rs:370-378)
-      // sbox_layer (src/traits.rs:326-358)
-      uint32_t t = C::mul(y, y, pl);
-      x = C::sub(x, C::mul_g(t, pl), kpl);
-      // x^(1/alpha): sliding window of F::kCoopWin bits, table of odd powers in LDS
-      {
-        const uint32_t x2 = C::mul(x, x, pl);
-        uint32_t pw = x;
-        tab[lane] = pw;
-#pragma nounroll
-        for (int i = 1; i < E; i++) {
-          pw = C::mul(pw, x2, pl);
-          tab[i * kBlock + lane] = pw;
-        }
-        uint32_t acc = tab[pc.first5 * kBlock + lane], tmp = acc;
-#pragma nounroll
-        for (int s = 0; s < pc.steps5; s++) {
-          const uint32_t word = pc.sched5[s];
-          const int nsq = word & 0xff, idx = word >> 8;
-          if (idx == 253) {  // leading-run doubling, see sliding_window() in tools/gen_params.py
-            tmp = acc;
-            continue;
-          }
-#pragma nounroll
-          for (int q = 0; q < nsq; q++) acc = C::mul(acc, acc, pl);
-          if (idx == 254) acc = C::mul(acc, tmp, pl);
-          else if (idx != 255) acc = C::mul(acc, tab[idx * kBlock + lane], pl);
-        }
-        t = acc;
-      }
-      y = C::sub(y, t, kpl);
-      t = C::mul(y, y, pl);
-      x = C::add(C::add(x, C::mul_g(t, pl)), delta);
+      coop_flystel<F, C>(x, y, pl, kpl, delta, tab, pc);  // sbox_layer (src/traits.rs:326-358)
     }
     // Jive feed-forward: state[0] + state[1] + elems[0] + elems[1] (anemoi_2_1/hasher.rs:102)
     const uint32_t s = C::add(C::add(x, y), C::add(e0, e1));
     const uint32_t o = C::to_abi(s, pl);
     if (live && j < NABI) out[item * NABI + j] = o;
+  }
+}
+
+// Anemoi-4-3 Jive on the row-cooperative arithmetic: TWO states per wavefront, a state's two columns on two
+// adjacent 16-lane rows (row 2s holds (x0, y0) = (state[0], state[2]), row 2s + 1 holds (x1, y1)) -- the lane-pair
+// idea of anemoi_perm.h one level up.  The two S-boxes of a round run side by side; only the linear layer
+// (mds_layer arm 2, src/traits.rs:143-157) couples the rows, through five cross-row exchanges per round.
+// K = 2: out[i] = e_i + e_{i+2} + s_i + s_{i+2} is row-local; K = 4: the two rows' sums are added
+// (anemoi_4_3/hasher.rs:148-179).
+template <int FIELD, int K>
+__global__ __launch_bounds__(kBlock) void k_jive4_coop(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                       size_t n, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using C = Coop29<F, 16>;
+  constexpr int NL = C::NL, NABI = C::NABI, R = F::kRounds43, E = 1 << (F::kCoopWin - 1), PER = 2;
+  __shared__ uint32_t tab[E * kBlock];
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16;
+  const uint32_t col = row & 1;
+  const bool odd = col != 0;
+  const uint32_t pl = C::konst(C::L::P), kpl = C::konst(C::L::KP), delta = C::konst(C::L::Delta);
+  auto other = [](uint32_t v) { return (uint32_t)__shfl_xor((int)v, 16); };   // the same limb of the partner row
+  // mds_layer arm NUM_COLUMNS = 2, statement by statement (the lane-pair form of anemoi_perm.h mds_pair):
+  //   s0 += g s1 ; s1 += g s0 ; s3 += g s2 ; s2 += g s3 ; swap(s2, s3) ; s2 += s0 ; s3 += s1 ; s0 += s2 ; s1 += s3
+  // Every cross-lane operation (the row exchange, the DPP carries inside add / mul_g) is executed by ALL lanes and
+  // the result selected afterwards: under divergent control flow a ds_bpermute reads nothing from inactive lanes.
+  auto mds = [&](uint32_t& x, uint32_t& y) {
+    uint32_t ox = other(x), oy = other(y);
+    uint32_t p = odd ? oy : ox;               // even: s1 (the odd row's x); odd: s2 (the even row's y)
+    uint32_t t = C::mul_g(p, pl);
+    uint32_t sx = C::add(x, t), sy = C::add(y, t);
+    x = odd ? x : sx;                         // even: s0 += g s1
+    y = odd ? sy : y;                         // odd:  s3 += g s2
+    ox = other(x), oy = other(y);
+    p = odd ? ox : oy;                        // odd: the updated s0; even: the updated s3
+    t = C::mul_g(p, pl);
+    sx = C::add(x, t), sy = C::add(y, t);
+    x = odd ? sx : x;                         // odd:  s1 += g s0
+    y = odd ? y : sy;                         // even: s2 += g s3
+    y = other(y);                             // swap(s2, s3)
+    y = C::add(y, x);                         // s2 += s0 ; s3 += s1
+    x = C::add(x, y);                         // s0 += s2 ; s1 += s3
+    x = C::settle(x, pl);
+    y = C::settle(y, pl);
+  };
+  const size_t groups = (n + PER - 1) / PER;
+  for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const size_t want = g * PER + row / 2;
+    const bool live = want < n;
+    const size_t item = live ? want : n - 1;
+    const uint32_t w0 = j < NABI ? in[(item * 4 + col) * NABI + j] : 0u;
+    const uint32_t w1 = j < NABI ? in[(item * 4 + 2 + col) * NABI + j] : 0u;
+    const uint32_t e0 = C::from_abi(w0, pl), e1 = C::from_abi(w1, pl);
+    uint32_t x = e0, y = e1;
+#pragma nounroll
+    for (int r = 0; r <= R; r++) {
+      if (r < R) {  // ark_layer: C[r * 2 + col], D[r * 2 + col]
+        x = C::add(x, j < NL ? pc.coop_c[(r * 2 + col) * NL + j] : 0u);
+        y = C::add(y, j < NL ? pc.coop_d[(r * 2 + col) * NL + j] : 0u);
+      }
+      mds(x, y);
+      if (r == R) break;
+      coop_flystel<F, C>(x, y, pl, kpl, delta, tab, pc);
+    }
+    uint32_t s = C::add(C::add(x, y), C::add(e0, e1));   // this column's share of the Jive sum
+    const uint32_t os = other(s);
+    if (K == 4) s = C::add(s, os);
+    const uint32_t o = C::to_abi(s, pl);
+    if (K == 2) {
+      if (live && j < NABI) out[(item * 2 + col) * NABI + j] = o;
+    } else {
+      if (live && !odd && j < NABI) out[item * NABI + j] = o;
+    }
   }
 }
 
@@ -720,7 +808,7 @@ namespace anemoi {
 
 struct HostConsts {  // what the context uploads for one (field, width)
   std::vector<uint32_t> ark_c, ark_d;    // lane-private limb layout (F::Lane)
-  std::vector<uint32_t> coop_c, coop_d;  // Anemoi-2-1 constants in the cooperative kernels' layout (F::Coop)
+  std::vector<uint32_t> coop_c, coop_d;  // the instance's round constants in the cooperative kernels' layout (F::Coop)
   std::vector<uint8_t> sched, sched5, sched_plain;
   int steps, first, steps5, first5, steps_plain, first_plain;
 };
@@ -777,8 +865,13 @@ struct Launch {
     hc->ark_c.assign(c, c + cnt);
     hc->ark_d.assign(d, d + cnt);
     using CL = typename F::Coop;
-    hc->coop_c.assign(CL::ArkC_21, CL::ArkC_21 + F::kRounds21 * CL::NL);
-    hc->coop_d.assign(CL::ArkD_21, CL::ArkD_21 + F::kRounds21 * CL::NL);
+    if (width == 2) {
+      hc->coop_c.assign(CL::ArkC_21, CL::ArkC_21 + F::kRounds21 * CL::NL);
+      hc->coop_d.assign(CL::ArkD_21, CL::ArkD_21 + F::kRounds21 * CL::NL);
+    } else {
+      hc->coop_c.assign(CL::ArkC_43, CL::ArkC_43 + 2 * F::kRounds43 * CL::NL);
+      hc->coop_d.assign(CL::ArkD_43, CL::ArkD_43 + 2 * F::kRounds43 * CL::NL);
+    }
     static_assert(WIN >= 2 && WIN <= 5, "schedules are generated for 2..5-bit windows");
     static_assert(F::kCoopWin >= 2 && F::kCoopWin <= 5, "");
     if (F::kCoopWin == 5) {
@@ -838,6 +931,13 @@ struct Launch {
       const size_t groups = (n + 3) / 4;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       k_jive2_coop<FIELD, 16><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
+      return hipGetLastError();
+    }
+    if (width == 4 && n <= coop43_max_items(F::Coop::NL)) {  // 4-3 latency path: two states per wavefront
+      const size_t groups = (n + 1) / 2;
+      const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      if (k == 2) k_jive4_coop<FIELD, 2><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
+      else k_jive4_coop<FIELD, 4><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
     if (width == 2)

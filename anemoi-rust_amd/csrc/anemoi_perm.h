@@ -85,7 +85,7 @@ struct PermConsts {
   const uint32_t* sched5;
   int steps5;
   int first5;
-  // Anemoi-2-1 round constants in the cooperative kernels' limb layout (F::Coop)
+  // the instance's round constants in the cooperative kernels' limb layout (F::Coop)
   const uint32_t* coop_c;
   const uint32_t* coop_d;
 };

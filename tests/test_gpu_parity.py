@@ -368,9 +368,10 @@ def test_cfg5_jubjub_merkle_depth14(A, oracle, params):
 
 def test_cooperative_and_lane_private_paths_agree(oracle, params):
     """Jive 2-1 has three kernels: wave-cooperative with one item per wavefront (small batches), row-cooperative
-    with four items per wavefront (one per 16-lane DPP row; medium batches) and lane-private (one item per lane).
-    ANEMOI_COOP_MAX / ANEMOI_COOP4_MAX force each for every size; all must match the oracle bit for bit on all 7
-    fields, ragged sizes (partly filled wavefronts and rows) and edge states."""
+    with four items per wavefront (one per 16-lane DPP row; medium batches) and lane-private (one item per lane);
+    Jive 4-3 has the row-cooperative form with two states per wavefront and the lane-pair kernel.
+    ANEMOI_COOP_MAX / ANEMOI_COOP4_MAX / ANEMOI_COOP43_MAX force each for every size; all must match the oracle bit
+    for bit on all 7 fields, ragged sizes (partly filled wavefronts and rows) and edge states."""
     import subprocess, sys, os
     from conftest import ROOT
     code = r'''
@@ -393,12 +394,21 @@ for fid, field in enumerate(A.FIELD_IDS):
         assert (got == oracle.compress_batch(fid, 2, st, threads=8)).all(), (field, n)
     leaves = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(64)])
     assert (A.Anemoi(field, 2).merkle_root(leaves, 6) == oracle.merkle_root(fid, leaves, 6)).all()
+    # Anemoi-4-3: the row-cooperative kernel (two states per wavefront) against the lane-pair kernel's oracle, k = 2 and 4
+    for n in (1, 2, 3, 33, 130):
+        st = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(4 * n)]).reshape(n, 4, L)
+        st[0] = 0
+        if n > 1:
+            st[1] = oracle.ints_to_mont(fid, [p - 1] * 4)
+        for k in (2, 4):
+            got = A.Anemoi(field, 4).compress_k_batch(st, k)
+            assert (got == oracle.compress_batch(fid, 4, st, k=k, threads=8)).all(), (field, n, k)
 print("ok")
 '''.replace("ROOT", repr(ROOT))
-    for coop_max, coop4_max in (("0", "0"), ("1000000000", "0"), ("0", "1000000000")):
-        env = dict(os.environ, ANEMOI_COOP_MAX=coop_max, ANEMOI_COOP4_MAX=coop4_max)
+    for coop_max, coop4_max, coop43_max in (("0", "0", "0"), ("1000000000", "0", "1000000000"), ("0", "1000000000", "1")):
+        env = dict(os.environ, ANEMOI_COOP_MAX=coop_max, ANEMOI_COOP4_MAX=coop4_max, ANEMOI_COOP43_MAX=coop43_max)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-        assert out.returncode == 0 and "ok" in out.stdout, (coop_max, coop4_max, out.stdout[-1500:], out.stderr[-1500:])
+        assert out.returncode == 0 and "ok" in out.stdout, (coop_max, coop4_max, coop43_max, out.stdout[-1500:], out.stderr[-1500:])
 
 
 def test_concurrent_callers(A, oracle, params):

@@ -59,6 +59,11 @@ for fid, field in enumerate(A.FIELD_IDS):
             del os.environ["ANEMOI_COOP_MAX"]
             msg += "  row-coop(3001): %s  wave-coop(700): %s" % ("ok" if ok2 else "MISMATCH", "ok" if ok4 else "MISMATCH")
             ok = ok and ok2 and ok4
+        else:  # Anemoi-4-3: a slice small enough for the row-cooperative kernel (two states per wavefront), k = 2 and 4
+            ok2 = (inst.compress_batch(st[:1501]) == exp[:1501]).all()
+            ok4 = (inst.compress_k_batch(st[:1501], 4) == oracle.compress_batch(fid, 4, st[:1501], k=4, threads=threads)).all()
+            msg += "  row-coop(1501): k=2 %s k=4 %s" % ("ok" if ok2 else "MISMATCH", "ok" if ok4 else "MISMATCH")
+            ok = ok and ok2 and ok4
         pg = inst.permutation_batch(st[:256])
         ok3 = all((pg[i] == oracle.permutation(fid, width, st[i])).all() for i in range(0, 256, 5))
         msg += "  permutation: %s" % ("ok" if ok3 else "MISMATCH")

@@ -79,3 +79,36 @@ for field in fields:
             if c4max and c4max <= c1max:
                 continue
             print("    coop1 <= %5d, coop4 <= %5d: %7.2f ms" % (c1max, c4max, tree_ms(depth, c1max, c4max)))
+
+# ---- Anemoi-4-3: row-cooperative (two states per wavefront) against the lane-pair kernel ---------------------------
+for field in [f for f in fields if f in ("bn_254", "bls12_381", "jubjub")] or ["bn_254", "bls12_381"]:
+    fid, L = A.field_id(field), synth.limbs_of(field)
+    sizes = [1 << k for k in range(0, 15)]
+    st = synth.states(field, 4, 0xC4, 0, sizes[-1])
+    d_in = torch.from_numpy(st.view(np.int64).reshape(-1)).to(dev)
+    print("%s Anemoi-4-3 Jive (k = 2): kernel time in ms per batch size" % field)
+    print("%8s %10s %10s   best" % ("states", "row-coop", "lane-pair"))
+
+    def timed43(n, d_out):
+        ts = []
+        for _ in range(6):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s)
+            assert A.lib.anemoi_jive_compress_k_dev(fid, 4, 2, d_in.data_ptr(), d_out.data_ptr(), n, s.cuda_stream) == 0
+            b.record(s)
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return sorted(ts[1:])[2]
+
+    for n in sizes:
+        row, ref = {}, None
+        for mode, cmax in (("row-coop", BIG), ("lane-pair", "0")):
+            os.environ["ANEMOI_COOP43_MAX"] = cmax
+            d_out = torch.zeros(n * 2 * L, dtype=torch.int64, device=dev)
+            row[mode] = timed43(n, d_out)
+            got = d_out.cpu()
+            if ref is None:
+                ref = got
+            assert torch.equal(ref, got), (field, n, mode)
+        print("%8d %10.3f %10.3f   %s" % (n, row["row-coop"], row["lane-pair"], min(row, key=row.get)))
+    os.environ.pop("ANEMOI_COOP43_MAX", None)
