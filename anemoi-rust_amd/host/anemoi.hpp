@@ -242,6 +242,40 @@ struct GenericInstance {
   }
 };
 
+// A run-time instance whose constants live on one device in the kernels' own form (anemoi_generic_prepare): the
+// device-pointer face of GenericInstance.  Buffers are raw device pointers (the caller's hipMalloc / tensor), calls are
+// asynchronous on `stream` (a hipStream_t as void*); the caller's current device must be `device`.
+template <int FIELD, int LIMBS>
+class PreparedGeneric {
+ public:
+  PreparedGeneric(const GenericInstance<FIELD, LIMBS>& g, int device = 0) : width_(g.state_width()) {
+    const auto inst = g.raw();
+    check(anemoi_generic_prepare(&inst, device, &h_));
+  }
+  ~PreparedGeneric() { (void)anemoi_generic_destroy(h_); }
+  PreparedGeneric(const PreparedGeneric&) = delete;
+  PreparedGeneric& operator=(const PreparedGeneric&) = delete;
+
+  size_t state_width() const { return width_; }
+  void permutation_dev(void* d_states, size_t n, void* stream = nullptr) const {
+    check(anemoi_generic_permutation_dev(h_, d_states, n, stream));
+  }
+  void compress_k_dev(size_t k, const void* d_in, void* d_out, size_t n, void* stream = nullptr) const {
+    if (k == 0 || width_ % k) throw std::invalid_argument("compress_k: STATE_WIDTH % k != 0");
+    check(anemoi_generic_jive_compress_k_dev(h_, int(k), d_in, d_out, n, stream));
+  }
+  void hash_field_dev(size_t rate, const void* d_elems, size_t elems_per_msg, size_t n, void* d_out, void* stream = nullptr) const {
+    check(anemoi_generic_hash_field_dev(h_, int(rate), d_elems, elems_per_msg, n, d_out, stream));
+  }
+  void hash_bytes_dev(size_t rate, const void* d_msgs, size_t msg_len, size_t n, void* d_out, void* stream = nullptr) const {
+    check(anemoi_generic_hash_bytes_dev(h_, int(rate), d_msgs, msg_len, n, d_out, stream));
+  }
+
+ private:
+  anemoi_generic_handle* h_ = nullptr;
+  size_t width_;
+};
+
 // the reference's 14 unit structs (src/<field>/anemoi_X_Y/mod.rs:37-38); rounds from :31
 using AnemoiBls12_381_2_1 = Instance<ANEMOI_BLS12_381, 2, 6, 21>;
 using AnemoiBls12_381_4_3 = Instance<ANEMOI_BLS12_381, 4, 6, 14>;

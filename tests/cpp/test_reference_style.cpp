@@ -81,6 +81,13 @@ static void run_line(const std::string& kind, const std::vector<std::string>& in
   }
 }
 
+// the three HIP runtime entry points the prepared-handle case needs (this file is built by g++, without the HIP headers)
+extern "C" {
+int hipMalloc(void** ptr, size_t size);
+int hipFree(void* ptr);
+int hipMemcpy(void* dst, const void* src, size_t size, int kind);
+}
+
 // a run-time instance (tests/golden/generic.json): in = rounds, has_mds, ARK_C, ARK_D, [MDS], state
 template <int FIELD, int L>
 static void run_generic(size_t cols, const std::vector<std::string>& in, const std::vector<std::string>& out) {
@@ -98,8 +105,21 @@ static void run_generic(size_t cols, const std::vector<std::string>& in, const s
   std::vector<Felt<L>> st, expected;
   for (size_t i = 0; i < 2 * cols; i++) st.push_back(felt(in[pos++]));
   for (auto& o : out) expected.push_back(felt(o));
+  const std::vector<Felt<L>> input = st;
   g.permutation_batch(st);
   EXPECT(st == expected, "generic permutation");
+  {  // the same instance prepared once, on device pointers (the HIP runtime's C entry points, declared below)
+    PreparedGeneric<FIELD, L> prep(g, 0);
+    const size_t bytes = input.size() * sizeof(Felt<L>);
+    void* d = nullptr;
+    EXPECT(hipMalloc(&d, bytes) == 0, "hipMalloc");
+    EXPECT(hipMemcpy(d, input.data(), bytes, 1 /* hipMemcpyHostToDevice */) == 0, "hipMemcpy H2D");
+    prep.permutation_dev(d, 1);
+    std::vector<Felt<L>> got(input.size());
+    EXPECT(hipMemcpy(got.data(), d, bytes, 2 /* hipMemcpyDeviceToHost */) == 0, "hipMemcpy D2H");   // synchronises
+    EXPECT(got == expected, "generic permutation through a prepared handle");
+    (void)hipFree(d);
+  }
   bool threw = false;
   try { g.compress_k_batch(expected, 2 * cols + 2); } catch (const std::invalid_argument&) { threw = true; }
   EXPECT(threw, "compress_k with k > STATE_WIDTH must be rejected");

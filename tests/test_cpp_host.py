@@ -14,7 +14,7 @@ LIBDIR = os.path.join(ROOT, "anemoi-rust_amd", "lib")
 def build(tmp_path):
     exe = str(tmp_path / "test_reference_style")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", SRC, "-o", exe, "-L" + LIBDIR, "-lanemoi_mi355x",
-                           "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-Wl,-rpath," + LIBDIR, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
