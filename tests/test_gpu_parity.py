@@ -4,6 +4,7 @@
   (3) size-independent properties at BASELINE.json's full sizes.
 Bit-exact everywhere (integer arithmetic).  Run on the GPU box: pytest -m gpu.
 """
+import os
 import random
 
 import numpy as np
@@ -30,10 +31,43 @@ def rand_elems(oracle, fid, modulus, count, seed):
     return oracle.ints_to_mont(fid, [rng.randrange(modulus) for _ in range(count)])
 
 
+class knobs:
+    """kernel-selection knobs for the duration of a with-block (the library reads them at every call)"""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.prev = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# small batches take the cooperative latency kernels by default; "lane" forces the lane-private throughput kernels
+LATENCY_KERNELS = {"default": {}, "lane": {"ANEMOI_COOP_MAX": 0, "ANEMOI_COOP4_MAX": 0, "ANEMOI_COOP43_MAX": 0,
+                                           "ANEMOI_COOP_SPONGE_MAX": 0}}
+
+
 # ---------------------------------------------------------------- (1) the reference's own KATs
 
+@pytest.mark.parametrize("kernels", ["default", "lane"])
 @pytest.mark.parametrize("field,width", INSTANCES)
-def test_reference_kats(A, kats, field, width):
+def test_reference_kats(A, kats, field, width, kernels):
+    with knobs(**LATENCY_KERNELS[kernels]):
+        check_reference_kats(A, kats, field, width)
+
+
+def check_reference_kats(A, kats, field, width):
     k, inst = kats[inst_key(field, width)], A.Anemoi(field, width)
     enc, dec = inst.encode, inst.decode
 
@@ -71,8 +105,16 @@ def test_reference_kats(A, kats, field, width):
 
 # ---------------------------------------------------------------- (2) differential vs the oracle
 
+@pytest.mark.parametrize("kernels", ["default", "lane"])
 @pytest.mark.parametrize("field,width", INSTANCES)
-def test_permutation_and_jive_vs_oracle(A, oracle, params, field, width):
+def test_permutation_and_jive_vs_oracle(A, oracle, params, field, width, kernels):
+    """batches of 1 .. 130 states: by default the row-cooperative kernels (k_jive2_coop / k_jive4_coop /
+    k_permutation_coop), with "lane" the lane-private / lane-pair throughput kernels"""
+    with knobs(**LATENCY_KERNELS[kernels]):
+        check_permutation_and_jive_vs_oracle(A, oracle, params, field, width)
+
+
+def check_permutation_and_jive_vs_oracle(A, oracle, params, field, width):
     fid, p = FIELD_IDS.index(field), int(params[field]["modulus"])
     inst, L = A.Anemoi(field, width), params[field]["u64_limbs"]
     # ragged batch sizes around the 64-lane workgroup
@@ -100,8 +142,15 @@ def test_permutation_and_jive_vs_oracle(A, oracle, params, field, width):
             assert (got[i] == oracle.merge(fid, width, pr[i, 0], pr[i, 1])).all()
 
 
+@pytest.mark.parametrize("kernels", ["default", "lane"])
 @pytest.mark.parametrize("field,width", INSTANCES)
-def test_sponge_vs_oracle(A, oracle, params, field, width):
+def test_sponge_vs_oracle(A, oracle, params, field, width, kernels):
+    """small batches: by default the row-cooperative sponge (k_sponge_coop), with "lane" the lane-private one"""
+    with knobs(**LATENCY_KERNELS[kernels]):
+        check_sponge_vs_oracle(A, oracle, params, field, width)
+
+
+def check_sponge_vs_oracle(A, oracle, params, field, width):
     fid, p = FIELD_IDS.index(field), int(params[field]["modulus"])
     inst, L, ch = A.Anemoi(field, width), params[field]["u64_limbs"], params[field]["byte_chunk"]
     rng = np.random.default_rng(fid * 10 + width)
@@ -138,10 +187,12 @@ def test_long_sponge_bound_stress(A, oracle, params, field, width):
     msgs = rng.integers(0, 256, size=(6, 3000), dtype=np.uint8)
     msgs[0] = 0xFF
     msgs[1] = 0
-    assert (inst.hash_batch(msgs) == oracle.hash_bytes_batch(fid, width, msgs, threads=6)).all()
     el = np.broadcast_to(oracle.ints_to_mont(fid, [p - 1]), (2, 40, L)).copy()
     el[1, ::2] = oracle.ints_to_mont(fid, [1])
-    assert (inst.hash_field_batch(el) == oracle.hash_field_batch(fid, width, el, threads=2)).all()
+    for kernels in ("default", "lane"):   # the row-cooperative and the lane-private sponge
+        with knobs(**LATENCY_KERNELS[kernels]):
+            assert (inst.hash_batch(msgs) == oracle.hash_bytes_batch(fid, width, msgs, threads=6)).all(), kernels
+            assert (inst.hash_field_batch(el) == oracle.hash_field_batch(fid, width, el, threads=2)).all(), kernels
 
 
 @pytest.mark.parametrize("field", FIELD_IDS)

@@ -128,7 +128,7 @@ def lds_dynamic(short, field):
     nl, nabi = LIMBS[field], ABI_WORDS[field]
     nq = (nl + 3) // 4
     tab = ((1 << (WIN - 1)) - 1) * nq * 16 * 64
-    if short.startswith("k_jive2_coop") or short.startswith("k_jive4_coop") or short.startswith("k_assemble"):
+    if "_coop<" in short or short.startswith("k_assemble") or short.startswith("k_generic_prepare"):
         return 0
     if short.startswith("k_mont_convert"):
         return nabi * 4 * 64

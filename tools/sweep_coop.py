@@ -112,3 +112,38 @@ for field in [f for f in fields if f in ("bn_254", "bls12_381", "jubjub")] or ["
             assert torch.equal(ref, got), (field, n, mode)
         print("%8d %10.3f %10.3f   %s" % (n, row["row-coop"], row["lane-pair"], min(row, key=row.get)))
     os.environ.pop("ANEMOI_COOP43_MAX", None)
+
+# ---- sponge: row-cooperative (4 / 2 messages per wavefront) against the lane-private kernels, 1 KB messages ----------
+for field, width in (("jubjub", 2), ("bn_254", 4), ("bls12_381", 2)):
+    if field not in fields and fields != ["jubjub", "bls12_381"]:
+        continue
+    fid, L = A.field_id(field), synth.limbs_of(field)
+    lib = A.lib
+    import ctypes
+    lib.anemoi_hash_bytes_dev.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+    mlen = 1024
+    sizes = [1 << k for k in range(0, 15, 2)]
+    msgs = torch.from_numpy(np.random.default_rng(5).integers(0, 256, size=(sizes[-1], mlen), dtype=np.uint8)).to(dev)
+    print("%s Anemoi-%s sponge, %d-byte messages: kernel time in ms per batch size" % (field, "2-1" if width == 2 else "4-3", mlen))
+    print("%8s %10s %10s   best" % ("messages", "row-coop", "lane"))
+    for n in sizes:
+        row, ref = {}, None
+        for mode, cmax in (("row-coop", BIG), ("lane", "0")):
+            os.environ["ANEMOI_COOP_SPONGE_MAX"] = cmax
+            d_out = torch.zeros(n * L, dtype=torch.int64, device=dev)
+            ts = []
+            for _ in range(3):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(s)
+                assert lib.anemoi_hash_bytes_dev(fid, width, msgs.data_ptr(), mlen, n, d_out.data_ptr(), s.cuda_stream) == 0
+                b.record(s)
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            row[mode] = min(ts[1:])
+            got = d_out.cpu()
+            if ref is None:
+                ref = got
+            assert torch.equal(ref, got), (field, n, mode)
+        print("%8d %10.3f %10.3f   %s" % (n, row["row-coop"], row["lane"], min(row, key=row.get)))
+    os.environ.pop("ANEMOI_COOP_SPONGE_MAX", None)
