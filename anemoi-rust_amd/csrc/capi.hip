@@ -421,7 +421,11 @@ int sponge_host(int field, int width, int bytes, const void* src, size_t per_msg
       // Few messages (cannot be cut by message), or long ones (a message chunk of one quantum would be hundreds of
       // MB of staging): feed blocks of at most one quantum of messages segment by segment.
       const size_t blk = count < 2 * quantum ? count : quantum;
-      if (want_segments(blk, per_msg_bytes, unit) && (count < 2 * quantum || quantum * per_msg_bytes > (size_t(256) << 20))) {
+      // (a batch small enough for the row-cooperative sponge is compute-bound by orders of magnitude -- one permutation
+      // per 1.4 ms against 93 bytes of input -- so it goes up in one piece and takes the latency kernel)
+      const bool latency_batch = count <= anemoi::coop_sponge_max_items(width, 0) && !getenv("ANEMOI_SPONGE_SEGMENT_BYTES");
+      if (!latency_batch && want_segments(blk, per_msg_bytes, unit) &&
+          (count < 2 * quantum || quantum * per_msg_bytes > (size_t(256) << 20))) {
         for (size_t b = 0; b < count; b += blk) {
           const size_t m = count - b < blk ? count - b : blk;
           int r = sponge_segments(ln, field, width, bytes, in + b * per_msg_bytes, per_msg, m, o + b * eb);
