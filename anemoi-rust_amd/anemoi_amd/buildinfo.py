@@ -33,11 +33,11 @@ def bls12_381_limb_layout():
                          r"\d+ split columns\), multiplication (\d+) \((\d+),", hdr):
         best = {"limb_bits": int(m.group(1)), "limbs": int(m.group(2)), "sqr_instr": int(m.group(3)),
                 "sqr_mad": int(m.group(4)), "mul_instr": int(m.group(5)), "mul_mad": int(m.group(6))}
-    body = hdr[hdr.index("template <> struct AsmMont<0, %d>" % best["limb_bits"]):]
-    body = body[:body.index("};")]
-    sq, mu = body.split("static __forceinline__ void mul(")
+    def body(kind):   # the string macro holding the statement's instructions
+        m = re.search(r"#define ANEMOI_ASM_%s_BODY_0_%d \\\n((?:[ \t]+\"[^\n]*\n)+)" % (kind, best["limb_bits"]), hdr)
+        return m.group(1)
     wide = lambda s: sum(s.count(op) for op in ("v_lshrrev_b64", "v_lshl_add_u64", "v_mul_lo_u32"))
-    best["sqr_wide"], best["mul_wide"] = wide(sq), wide(mu)
+    best["sqr_wide"], best["mul_wide"] = wide(body("SQR")), wide(body("MUL"))
     return best
 
 

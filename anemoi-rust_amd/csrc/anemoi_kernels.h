@@ -8,8 +8,12 @@
 //   k_mont_convert  canonical <-> Montgomery           (arkworks into_bigint / from_bigint)
 // one Anemoi-4-3 state per lane PAIR (both columns' S-boxes run side by side):
 //   k_permutation_pair, k_jive_pair, k_sponge_pair      (all width-4 entry points)
-// one item per wavefront (latency path, small batches):
-//   k_jive2_coop    Jive::compress 2-1 / Sponge::merge on the wave-cooperative arithmetic of coop29.h
+// a few items per wavefront, one 29-bit limb per lane (latency path for small batches, coop29.h):
+//   k_jive2_coop<F, 16>   Jive::compress 2-1 / Sponge::merge, four items per wavefront (one per 16-lane DPP row);
+//                         <F, 64> = rounds 1-2's one item per wavefront, kept for A/B
+//   k_jive4_coop          Jive::compress(_k) 4-3, two states per wavefront (a column per row)
+//   k_sponge_coop         Sponge::hash / hash_field on small batches of equal-length messages
+//   k_permutation_coop, k_merkle_climb_coop   Anemoi::permutation / path verification on small batches
 // instances given by run-time trait constants, one state per NUM_COLUMNS lanes (anemoi_generic.h):
 //   k_permutation_cols, k_jive_cols, k_sponge_cols, and the element-wise k_exp_alpha
 //
@@ -657,7 +661,7 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, uint32_t 
     uint32_t acc = tab[pc.first5 * kBlock + lane], tmp = acc;
 #pragma nounroll
     for (int s = 0; s < pc.steps5; s++) {
-      const uint32_t word = pc.sched5[s];
+      const uint32_t word = uniform_word(pc.sched5, s);
       const int nsq = word & 0xff, idx = word >> 8;
       if (idx == 253) {  // leading-run doubling, see sliding_window() in tools/gen_params.py
         tmp = acc;

@@ -127,6 +127,22 @@ __device__ __forceinline__ void xdigit_build(typename A::Fe& r, const typename A
 // in VGPRs (digits and schedule chosen per field by tools/gen_params.py: e.g. 51 = 0b110011 and 59 for BLS12-381,
 // 468 products instead of 478 -- the LDS budget of 3-4 waves per SIMD stops at three entries, the register
 // budget has room for these); a multiplication by such a digit takes its operand straight from the registers.
+// One word of a wave-uniform device table (the exponent schedule) through the SCALAR cache.  Written as a plain
+// `table[i]`, hipcc cannot prove that nothing in the kernel clobbers the table and fetches it with a vector load +
+// v_readfirstlane + s_waitcnt vmcnt(0): a vector-memory round trip in front of every step of the exponentiation
+// (54-80 per S-box).  Three or four resident wavefronts hide that; a lone wavefront (the latency kernels, the middle
+// levels of a Merkle tree) or two (config 3) do not: in-process A/B (profiles/r03/ab_scalar_schedule_loads.txt) one
+// cooperative compression -1.5 %, 4 096 of them -5 %, lane-private batches of 2^15 .. 2^16 items -2.5 .. -8.8 %, full
+// batches unchanged.  The tables are written once by the host before any launch, so reading them through the constant
+// address space is exact.  (Restructuring the exponentiation into ONE loop with ONE multiplication statement, which
+// removes the ~39 v_mov per step hipcc places around the squaring loop and the per-operand multiplications, was built
+// and measured in the same A/B: no gain on full batches -- v_mov is nearly free next to v_mad_u64_u32 -- and a loss
+// on underfilled ones, because the schedule load then sits right in front of its use.  Not adopted.)
+__device__ __forceinline__ uint32_t uniform_word(const uint32_t* table, int i) {
+  typedef const uint32_t __attribute__((address_space(4))) * ConstWords;
+  return ((ConstWords)(uintptr_t)table)[i];
+}
+
 template <class F, class A, int WIN, bool USEX = true>
 __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename A::Fe& x, const PermConsts& pc,
                                               const LdsTable<A>& tab) {
@@ -155,7 +171,7 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
   if constexpr (F::kChainTmp) tmp = acc;
 #pragma nounroll
   for (int s = 0; s < steps; s++) {
-    const uint32_t word = sched[s];
+    const uint32_t word = uniform_word(sched, s);
     const int nsq = word & 0xff, idx = word >> 8;
     if constexpr (F::kChainTmp) {
       if (idx == 253) {

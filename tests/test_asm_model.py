@@ -24,20 +24,25 @@ M32, M64 = (1 << 32) - 1, (1 << 64) - 1
 
 
 def parse_header():
-    """{(field_id, W): {"NL": nl, "sqr": (lines, operands), "mul": (lines, operands)}}"""
+    """{(field_id, W): {"NL": nl, "sqr": (lines, outs, ins), "mul": (lines, outs, ins)}} from the generated header: the
+    bodies are string macros (ANEMOI_ASM_{SQR,MUL}_BODY_f_W) shared by the struct's functions and the ANEMOI_PIN_* macros;
+    the squaring's inputs are the limbs of p and n0inv (ANEMOI_ASM_SQR_INS_f_W, SGPR operands), the multiplication's the
+    limbs of b (VGPR operands)"""
     text = open(HDR).read()
     out = {}
     for m in re.finditer(r"template <> struct AsmMont<(\d+), (\d+)> \{(.*?)\n\};", text, re.S):
         fid, W, body = int(m.group(1)), int(m.group(2)), m.group(3)
         nl = int(re.search(r"NL = (\d+);", body).group(1))
         entry = {"NL": nl}
+        outs = [("a", str(i)) for i in range(nl)]
         for name in ("sqr", "mul"):
-            fn = re.search(r"void %s\(.*?asm volatile\((.*?)\);\s*\}" % name, body, re.S).group(1)
-            lines = re.findall(r'"([^"]+?)\\n\\t"', fn)
-            tail = fn[fn.rindex('\\n\\t"') + 5:]
-            parts = [s.strip() for s in tail.split("\n") if s.strip().startswith(":")]
-            outs = re.findall(r'"\+v"\((\w+)\[(\d+)\]\)', parts[0])
-            ins = re.findall(r'"(s|v)"\((?:0x([0-9a-f]+)u|(\w+)\[(\d+)\])\)', parts[1])
+            mb = re.search(r"#define ANEMOI_ASM_%s_BODY_%d_%d \\\n((?:[ \t]+\"[^\n]*\n)+)" % (name.upper(), fid, W), text)
+            lines = re.findall(r'"([^"]+?)\\n\\t"', mb.group(1))
+            if name == "sqr":
+                mi = re.search(r"#define ANEMOI_ASM_SQR_INS_%d_%d (.*)" % (fid, W), text).group(1)
+                ins = [("s", h, "", "") for h in re.findall(r'"s"\(0x([0-9a-f]+)u\)', mi)]
+            else:
+                ins = [("v", "", "b", str(i)) for i in range(nl)]
             entry[name] = (lines, outs, ins)
         out[(fid, W)] = entry
     return out

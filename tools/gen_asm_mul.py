@@ -448,6 +448,11 @@ def main():
          "// column carry is the accumulator's initial value).  See the generator's docstring.",
          "#pragma once", "#include <hip/hip_runtime.h>", "#include <cstdint>", "namespace anemoi {",
          "template <int FIELD, int W> struct AsmMont;"]
+    def macro(name, lines):
+        """a multi-line string-literal macro holding an asm body"""
+        return "#define %s \\\n" % name + " \\\n".join('        "%s\\n\\t"' % l for l in lines)
+
+    pinned = []   # (fid, W, nl) of every layout, for the dispatcher macros below
     for fid, name in enumerate(FIELD_IDS):
         p = int(params[name]["modulus"])
         for W in ((29, 30) if p.bit_length() > 300 else (29,)):
@@ -455,23 +460,46 @@ def main():
             sq, sq_clob, sq_splits, sq_light = gen_sqr(nl, pl, n0, W, p)
             mu, mu_clob, mu_splits, mu_light = gen_mul(nl, pl, n0, W, p)
             nmad = sum(1 for l in sq if l.startswith("v_mad"))
+            tag = "%d_%d" % (fid, W)
             h.append("// %s, %d-bit limbs: %d limbs; squaring %d instructions (%d v_mad_u64_u32, %d split columns), "
                      "multiplication %d (%d, %d)" % (name, W, nl, len(sq), nmad, sq_splits, len(mu),
                                                      sum(1 for l in mu if l.startswith("v_mad")), mu_splits))
             h.append("//   32-bit column carries (v_alignbit_b32 instead of v_lshrrev_b64): %d of %d columns (squaring), "
                      "%d (multiplication)" % (sq_light, 2 * nl - 1, mu_light))
+            # the bodies as string macros: used by the struct's functions (operands = array elements) and by the
+            # ANEMOI_PIN_* macros (operands = local register variables pinned to fixed VGPRs, anemoi_perm.h)
+            h.append(macro("ANEMOI_ASM_SQR_BODY_" + tag, sq))
+            h.append("#define ANEMOI_ASM_SQR_INS_%s %s" % (tag, ", ".join(['"s"(0x%xu)' % v for v in pl] + ['"s"(0x%xu)' % n0])))
+            h.append("#define ANEMOI_ASM_SQR_CLOB_%s %s" % (tag, ", ".join('"%s"' % c for c in sq_clob)))
+            h.append(macro("ANEMOI_ASM_MUL_BODY_" + tag, mu))
+            h.append("#define ANEMOI_ASM_MUL_CLOB_%s %s" % (tag, ", ".join('"%s"' % c for c in mu_clob)))
+            A = ["A%d" % i for i in range(nl)]
+            h.append("#define ANEMOI_PIN_SQR_%s(%s) asm volatile(ANEMOI_ASM_SQR_BODY_%s : %s : ANEMOI_ASM_SQR_INS_%s : ANEMOI_ASM_SQR_CLOB_%s)"
+                     % (tag, ", ".join(A), tag, ", ".join('"+v"(%s)' % a for a in A), tag, tag))
+            h.append("#define ANEMOI_PIN_MUL_%s(%s, B) asm volatile(ANEMOI_ASM_MUL_BODY_%s : %s : %s : ANEMOI_ASM_MUL_CLOB_%s)"
+                     % (tag, ", ".join(A), tag, ", ".join('"+v"(%s)' % a for a in A),
+                        ", ".join('"v"((B)[%d])' % i for i in range(nl)), tag))
             h.append("template <> struct AsmMont<%d, %d> {" % (fid, W))
             h.append("  static constexpr int NL = %d;" % nl)
             h.append("  __device__ static __forceinline__ void sqr(uint32_t (&a)[NL]) {")
-            outs = ['"+v"(a[%d])' % i for i in range(nl)]
-            ins = ['"s"(0x%xu)' % v for v in pl] + ['"s"(0x%xu)' % n0]
-            h.append(emit("sqr", sq, outs, ins, sq_clob))
+            h.append("    ANEMOI_PIN_SQR_%s(%s);" % (tag, ", ".join("a[%d]" % i for i in range(nl))))
             h.append("  }")
             h.append("  __device__ static __forceinline__ void mul(uint32_t (&a)[NL], const uint32_t (&b)[NL]) {")
-            ins = ['"v"(b[%d])' % i for i in range(nl)]
-            h.append(emit("mul", mu, outs, ins, mu_clob))
+            h.append("    ANEMOI_PIN_MUL_%s(%s, b);" % (tag, ", ".join("a[%d]" % i for i in range(nl))))
             h.append("  }")
             h.append("};")
+            pinned.append((fid, W, nl))
+    # dispatchers: ANEMOI_PIN_SQR(FID, W, q) / ANEMOI_PIN_MUL(FID, W, q, B) on the variables q0 .. q13 of the calling scope
+    # (FID, W compile-time constants of a template; the branches not taken are discarded)
+    def chain(kind, extra):
+        out = []
+        for k, (fid, W, nl) in enumerate(pinned):
+            args = ", ".join("Q##%d" % i for i in range(nl)) + extra
+            out.append("  %sif constexpr ((FID) == %d && (W_) == %d) { ANEMOI_PIN_%s_%d_%d(%s); }"
+                       % ("else " if k else "", fid, W, kind, fid, W, args))
+        return " \\\n".join(out)
+    h.append("#define ANEMOI_PIN_SQR(FID, W_, Q) \\\n" + chain("SQR", ""))
+    h.append("#define ANEMOI_PIN_MUL(FID, W_, Q, B) \\\n" + chain("MUL", ", B"))
     h.append("// Wave-cooperative product (coop29.h), always on 29-bit limbs: see gen_coop_mul() in the generator.")
     h.append("template <int FIELD> struct AsmCoop;")
     for fid, name in enumerate(FIELD_IDS):
