@@ -643,19 +643,19 @@ inline size_t coop43_max_items(int limbs29) {
 // Flystel S-box (src/traits.rs:326-358) on the cooperative arithmetic: x -= g y^2 ; y -= x^(1/alpha) ; x += g y^2 + delta,
 // the exponentiation by a sliding window of F::kCoopWin bits over odd powers held in LDS (one word per lane and entry)
 template <class F, class C>
-__device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, uint32_t pl, uint32_t kpl, uint32_t delta,
-                                             uint32_t* tab, const PermConsts& pc) {
+__device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typename C::K& k, uint32_t* tab,
+                                             const PermConsts& pc) {
   constexpr int E = 1 << (F::kCoopWin - 1);
   const uint32_t lane = threadIdx.x;
-  uint32_t t = C::mul(y, y, pl);
-  x = C::sub(x, C::mul_g(t, pl), kpl);
+  uint32_t t = C::mul(y, y, k.pl);
+  x = C::sub(x, C::mul_g(t, k), k.kpl);
   {
-    const uint32_t x2 = C::mul(x, x, pl);
+    const uint32_t x2 = C::mul(x, x, k.pl);
     uint32_t pw = x;
     tab[lane] = pw;
 #pragma nounroll
     for (int i = 1; i < E; i++) {
-      pw = C::mul(pw, x2, pl);
+      pw = C::mul(pw, x2, k.pl);
       tab[i * kBlock + lane] = pw;
     }
     uint32_t acc = tab[pc.first5 * kBlock + lane], tmp = acc;
@@ -667,16 +667,19 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, uint32_t 
         tmp = acc;
         continue;
       }
+      // the step's table operand is read from LDS BEFORE its squarings (a lone wavefront would otherwise sit out the
+      // LDS latency in front of every multiplication)
+      const uint32_t opnd = idx < 253 ? tab[idx * kBlock + lane] : 0u;
 #pragma nounroll
-      for (int q = 0; q < nsq; q++) acc = C::mul(acc, acc, pl);
-      if (idx == 254) acc = C::mul(acc, tmp, pl);
-      else if (idx != 255) acc = C::mul(acc, tab[idx * kBlock + lane], pl);
+      for (int q = 0; q < nsq; q++) acc = C::mul(acc, acc, k.pl);
+      if (idx == 254) acc = C::mul(acc, tmp, k.pl);
+      else if (idx != 255) acc = C::mul(acc, opnd, k.pl);
     }
     t = acc;
   }
-  y = C::sub(y, t, kpl);
-  t = C::mul(y, y, pl);
-  x = C::add(C::add(x, C::mul_g(t, pl)), delta);
+  y = C::sub(y, t, k.kpl);
+  t = C::mul(y, y, k.pl);
+  x = C::add(C::add(x, C::mul_g(t, k)), k.delta);
 }
 
 // Anemoi::permutation (src/traits.rs:370-378) on the cooperative arithmetic, for one column (x, y) per element row.
@@ -688,18 +691,21 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, uint32_t 
 //          inside add / mul_g) is executed by ALL lanes and the result selected afterwards: under divergent control
 //          flow a ds_bpermute reads nothing from inactive lanes.
 template <class F, class C, int W>
-__device__ __forceinline__ void coop_permutation(uint32_t& x, uint32_t& y, uint32_t pl, uint32_t kpl, uint32_t delta,
-                                                 uint32_t* tab, const PermConsts& pc) {
+__device__ __forceinline__ void coop_permutation(uint32_t& x, uint32_t& y, const typename C::K& k, uint32_t* tab,
+                                                 const PermConsts& pc) {
   constexpr int NL = C::NL, R = W == 2 ? F::kRounds21 : F::kRounds43;
   const uint32_t j = C::limb(), col = W == 4 ? ((threadIdx.x / 16) & 1) : 0;
   const bool odd = col != 0;
   auto other = [](uint32_t v) { return (uint32_t)__shfl_xor((int)v, 16); };   // the same limb of the partner row
+  // round constants: the NEXT round's pair is fetched while this round's S-box runs (vector loads, one limb per lane)
+  auto konst = [&](const uint32_t* tabk, int r) { return j < NL ? tabk[(r * (W / 2) + int(col)) * NL + j] : 0u; };
+  uint32_t kc = konst(pc.coop_c, 0), kd = konst(pc.coop_d, 0);
 #pragma nounroll
   for (int r = 0; r <= R; r++) {
     if (r < R) {  // ark_layer (src/traits.rs:111-125): C[r * c + col], D[r * c + col]
-      const int at = (r * (W / 2) + int(col)) * NL;
-      x = C::add(x, j < NL ? pc.coop_c[at + j] : 0u);
-      y = C::add(y, j < NL ? pc.coop_d[at + j] : 0u);
+      x = C::add(x, kc);
+      y = C::add(y, kd);
+      if (r + 1 < R) kc = konst(pc.coop_c, r + 1), kd = konst(pc.coop_d, r + 1);
     }
     if constexpr (W == 2) {
       y = C::add(y, x);
@@ -708,13 +714,13 @@ __device__ __forceinline__ void coop_permutation(uint32_t& x, uint32_t& y, uint3
       // s0 += g s1 ; s1 += g s0 ; s3 += g s2 ; s2 += g s3 ; swap(s2, s3) ; s2 += s0 ; s3 += s1 ; s0 += s2 ; s1 += s3
       uint32_t ox = other(x), oy = other(y);
       uint32_t p = odd ? oy : ox;               // even: s1 (the odd row's x); odd: s2 (the even row's y)
-      uint32_t t = C::mul_g(p, pl);
+      uint32_t t = C::mul_g(p, k);
       uint32_t sx = C::add(x, t), sy = C::add(y, t);
       x = odd ? x : sx;                         // even: s0 += g s1
       y = odd ? sy : y;                         // odd:  s3 += g s2
       ox = other(x), oy = other(y);
       p = odd ? ox : oy;                        // odd: the updated s0; even: the updated s3
-      t = C::mul_g(p, pl);
+      t = C::mul_g(p, k);
       sx = C::add(x, t), sy = C::add(y, t);
       x = odd ? sx : x;                         // odd:  s1 += g s0
       y = odd ? y : sy;                         // even: s2 += g s3
@@ -722,10 +728,10 @@ __device__ __forceinline__ void coop_permutation(uint32_t& x, uint32_t& y, uint3
       y = C::add(y, x);                         // s2 += s0 ; s3 += s1
       x = C::add(x, y);                         // s0 += s2 ; s1 += s3
     }
-    x = C::settle(x, pl);  // back below 2p
-    y = C::settle(y, pl);
+    x = C::settle(x, k);  // back below 2p
+    y = C::settle(y, k);
     if (r == R) break;  // permutation = R rounds + a final mds_layer
-    coop_flystel<F, C>(x, y, pl, kpl, delta, tab, pc);  // sbox_layer (src/traits.rs:326-358)
+    coop_flystel<F, C>(x, y, k, tab, pc);  // sbox_layer (src/traits.rs:326-358)
   }
 }
 
@@ -737,7 +743,7 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
   constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = kBlock / LPR;
   __shared__ uint32_t tab[E * kBlock];
   const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR;
-  const uint32_t pl = C::konst(C::L::P), kpl = C::konst(C::L::KP), delta = C::konst(C::L::Delta);
+  const typename C::K k = C::load_consts();
   const size_t groups = (n + PER - 1) / PER;   // a wavefront works on PER consecutive items
   for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
     const size_t want = g * PER + row;
@@ -745,12 +751,12 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
     const size_t item = live ? want : n - 1;   // rows beyond the batch redo the last item (all rows run the same code)
     const uint32_t w0 = j < NABI ? in[(item * 2 + 0) * NABI + j] : 0u;
     const uint32_t w1 = j < NABI ? in[(item * 2 + 1) * NABI + j] : 0u;
-    const uint32_t e0 = C::from_abi(w0, pl), e1 = C::from_abi(w1, pl);
+    const uint32_t e0 = C::from_abi(w0, k), e1 = C::from_abi(w1, k);
     uint32_t x = e0, y = e1;
-    coop_permutation<F, C, 2>(x, y, pl, kpl, delta, tab, pc);
+    coop_permutation<F, C, 2>(x, y, k, tab, pc);
     // Jive feed-forward: state[0] + state[1] + elems[0] + elems[1] (anemoi_2_1/hasher.rs:102)
     const uint32_t s = C::add(C::add(x, y), C::add(e0, e1));
-    const uint32_t o = C::to_abi(s, pl);
+    const uint32_t o = C::to_abi(s, k);
     if (live && j < NABI) out[item * NABI + j] = o;
   }
 }
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(kBlock) void k_jive4_coop(const uint32_t* __restric
   __shared__ uint32_t tab[E * kBlock];
   const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16, col = row & 1;
   const bool odd = col != 0;
-  const uint32_t pl = C::konst(C::L::P), kpl = C::konst(C::L::KP), delta = C::konst(C::L::Delta);
+  const typename C::K k = C::load_consts();
   const size_t groups = (n + PER - 1) / PER;
   for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
     const size_t want = g * PER + row / 2;
@@ -775,13 +781,13 @@ __global__ __launch_bounds__(kBlock) void k_jive4_coop(const uint32_t* __restric
     const size_t item = live ? want : n - 1;
     const uint32_t w0 = j < NABI ? in[(item * 4 + col) * NABI + j] : 0u;
     const uint32_t w1 = j < NABI ? in[(item * 4 + 2 + col) * NABI + j] : 0u;
-    const uint32_t e0 = C::from_abi(w0, pl), e1 = C::from_abi(w1, pl);
+    const uint32_t e0 = C::from_abi(w0, k), e1 = C::from_abi(w1, k);
     uint32_t x = e0, y = e1;
-    coop_permutation<F, C, 4>(x, y, pl, kpl, delta, tab, pc);
+    coop_permutation<F, C, 4>(x, y, k, tab, pc);
     uint32_t s = C::add(C::add(x, y), C::add(e0, e1));   // this column's share of the Jive sum
     const uint32_t os = (uint32_t)__shfl_xor((int)s, 16);
     if (K == 4) s = C::add(s, os);
-    const uint32_t o = C::to_abi(s, pl);
+    const uint32_t o = C::to_abi(s, k);
     if (K == 2) {
       if (live && j < NABI) out[(item * 2 + col) * NABI + j] = o;
     } else {
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(kBlock) void k_permutation_coop(uint32_t* __restric
   constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? 4 : 2;
   __shared__ uint32_t tab[E * kBlock];
   const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16, col = W == 4 ? (row & 1) : 0;
-  const uint32_t pl = C::konst(C::L::P), kpl = C::konst(C::L::KP), delta = C::konst(C::L::Delta);
+  const typename C::K k = C::load_consts();
   const size_t groups = (n + PER - 1) / PER;
   for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
     const size_t want = g * PER + (W == 2 ? row : row / 2);
@@ -807,9 +813,9 @@ __global__ __launch_bounds__(kBlock) void k_permutation_coop(uint32_t* __restric
     const size_t item = live ? want : n - 1;
     uint32_t* sx = states + (item * W + col) * NABI;          // state[col]
     uint32_t* sy = states + (item * W + W / 2 + col) * NABI;  // state[c + col]
-    uint32_t x = C::from_abi(j < NABI ? sx[j] : 0u, pl), y = C::from_abi(j < NABI ? sy[j] : 0u, pl);
-    coop_permutation<F, C, W>(x, y, pl, kpl, delta, tab, pc);
-    const uint32_t ox = C::to_abi(x, pl), oy = C::to_abi(y, pl);
+    uint32_t x = C::from_abi(j < NABI ? sx[j] : 0u, k), y = C::from_abi(j < NABI ? sy[j] : 0u, k);
+    coop_permutation<F, C, W>(x, y, k, tab, pc);
+    const uint32_t ox = C::to_abi(x, k), oy = C::to_abi(y, k);
     if (live && j < NABI) {
       sx[j] = ox;
       sy[j] = oy;
@@ -829,24 +835,24 @@ __global__ __launch_bounds__(kBlock) void k_merkle_climb_coop(const uint32_t* __
   constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = 4;
   __shared__ uint32_t tab[E * kBlock];
   const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16;
-  const uint32_t pl = C::konst(C::L::P), kpl = C::konst(C::L::KP), delta = C::konst(C::L::Delta);
+  const typename C::K k = C::load_consts();
   const size_t groups = (n + PER - 1) / PER;
   for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
     const size_t want = g * PER + row;
     const bool live = want < n;
     const size_t item = live ? want : n - 1;
     const uint64_t idx = index[item];
-    uint32_t cur = C::from_abi(j < NABI ? leaves[item * NABI + j] : 0u, pl);
+    uint32_t cur = C::from_abi(j < NABI ? leaves[item * NABI + j] : 0u, k);
 #pragma nounroll
     for (unsigned l = 0; l < depth; l++) {
-      const uint32_t sib = C::from_abi(j < NABI ? paths[(item * depth + l) * NABI + j] : 0u, pl);
+      const uint32_t sib = C::from_abi(j < NABI ? paths[(item * depth + l) * NABI + j] : 0u, k);
       const bool right = (idx >> l) & 1;   // this node is the right child: state = [sibling, node]
       uint32_t x = right ? sib : cur, y = right ? cur : sib;
       const uint32_t sum = C::add(cur, sib);
-      coop_permutation<F, C, 2>(x, y, pl, kpl, delta, tab, pc);
-      cur = C::settle(C::add(C::add(x, y), sum), pl);   // Jive feed-forward, back below 2p for the next level
+      coop_permutation<F, C, 2>(x, y, k, tab, pc);
+      cur = C::settle(C::add(C::add(x, y), sum), k);   // Jive feed-forward, back below 2p for the next level
     }
-    const uint32_t o = C::to_abi(cur, pl);
+    const uint32_t o = C::to_abi(cur, k);
     if (live && j < NABI) out[item * NABI + j] = o;
   }
 }
@@ -867,8 +873,7 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
   __shared__ uint32_t tab[E * kBlock];
   const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16, col = W == 4 ? (row & 1) : 0;
   const bool odd = col != 0;
-  const uint32_t pl = C::konst(C::L::P), kpl = C::konst(C::L::KP), delta = C::konst(C::L::Delta);
-  const uint32_t rr = C::konst(C::L::RR), one = C::konst(C::L::One);
+  const typename C::K k = C::load_consts();
   const size_t num = BYTES ? (per_msg + F::kChunk - 1) / F::kChunk : per_msg;
   const size_t total = num + (num % RATE == 0 ? 0 : 1);
   const size_t groups = (n + PER - 1) / PER;
@@ -883,7 +888,7 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
     for (size_t e = 0; e < total; e++) {
       uint32_t el;
       if (e >= num) {
-        el = one;
+        el = k.one;
       } else if (BYTES) {
         const size_t c0 = e * F::kChunk, left = per_msg - c0;
         const int clen = left < size_t(F::kChunk) ? int(left) : F::kChunk;
@@ -900,10 +905,10 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
           v |= uint64_t(byte) << (8 * t);
         }
         const uint32_t limb = j < NL ? uint32_t(v >> sh) & C::MASK : 0u;
-        el = C::mul(limb, rr, pl);            // plain integer < p -> Montgomery form
+        el = C::mul(limb, k.rr, k.pl);            // plain integer < p -> Montgomery form
       } else {
         const uint32_t w = j < NABI ? ((const uint32_t*)msg)[e * NABI + j] : 0u;
-        el = C::from_abi(w, pl);
+        el = C::from_abi(w, k);
       }
       // pos is wave-uniform (every message has the same length)
       const uint32_t sx = C::add(x, el), sy = C::add(y, el);
@@ -915,11 +920,11 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
       }
       pos++;
       if (pos == RATE || e == total - 1) {
-        coop_permutation<F, C, W>(x, y, pl, kpl, delta, tab, pc);
+        coop_permutation<F, C, W>(x, y, k, tab, pc);
         pos = 0;
       }
     }
-    const uint32_t o = C::to_abi(x, pl);   // digest = state[0]
+    const uint32_t o = C::to_abi(x, k);   // digest = state[0]
     if (live && !odd && j < NABI) out[item * NABI + j] = o;
   }
 }

@@ -55,6 +55,17 @@ struct Coop29 {
   __device__ static __forceinline__ uint32_t konst(const uint32_t* __restrict__ k) {
     return limb() < NL ? k[limb()] : 0u;
   }
+  // The field constants a kernel needs, fetched ONCE (one vector load each): p, the subtraction pad, delta, R' mod p
+  // (settle), g R' (mul_g of the tight fields) and the two ABI conversion factors.  Fetched where they are used -- as
+  // rounds 1-2 did for One / GMont / In / Out -- a lone wavefront sits out a vector-memory round trip in front of
+  // every settle() and mul_g(): four per round.
+  struct K {
+    uint32_t pl, kpl, delta, one, gm, in, out, rr;
+  };
+  __device__ static __forceinline__ K load_consts() {
+    return K{konst(L::P), konst(L::KP), konst(L::Delta), konst(L::One), konst(L::GMont), konst(L::In), konst(L::Out),
+             konst(L::RR)};
+  }
 
   // two carry passes: 64-bit column sums -> limbs < 2^29 + 2^7
   __device__ static __forceinline__ uint32_t settle_columns(uint64_t t) {
@@ -129,12 +140,12 @@ struct Coop29 {
   }
 
   // g * x (mul_by_generator, src/traits.rs:78-91)
-  __device__ static __forceinline__ uint32_t mul_g(uint32_t x, uint32_t pl) {
-    if constexpr (kTight) return mul(x, konst(L::GMont), pl);
+  __device__ static __forceinline__ uint32_t mul_g(uint32_t x, const K& k) {
+    if constexpr (kTight) return mul(x, k.gm, k.pl);
     return settle_columns((uint64_t)x * (uint32_t)F::kG);
   }
 
-  __device__ static __forceinline__ uint32_t settle(uint32_t x, uint32_t pl) { return mul(x, konst(L::One), pl); }
+  __device__ static __forceinline__ uint32_t settle(uint32_t x, const K& k) { return mul(x, k.one, k.pl); }
 
   // x < 2p -> x mod p, exact limbs
   __device__ static __forceinline__ uint32_t canonical(uint32_t x, uint32_t pl) {
@@ -164,11 +175,11 @@ struct Coop29 {
     if (58 - off < 32) v |= l2 << (58 - off);
     return limb() < NABI ? v : 0u;
   }
-  __device__ static __forceinline__ uint32_t from_abi(uint32_t w, uint32_t pl) {
-    return mul(words_to_limbs(w), konst(L::In), pl);
+  __device__ static __forceinline__ uint32_t from_abi(uint32_t w, const K& k) {
+    return mul(words_to_limbs(w), k.in, k.pl);
   }
-  __device__ static __forceinline__ uint32_t to_abi(uint32_t x, uint32_t pl) {
-    return limbs_to_words(canonical(mul(x, konst(L::Out), pl), pl));
+  __device__ static __forceinline__ uint32_t to_abi(uint32_t x, const K& k) {
+    return limbs_to_words(canonical(mul(x, k.out, k.pl), k.pl));
   }
 };
 
