@@ -1,0 +1,348 @@
+// anemoi_coop_kernels.h -- the LATENCY kernels: small batches on the row-cooperative arithmetic of coop29.h (one 29-bit
+// limb per lane, an element per 16-lane DPP row), and the cut-offs that route a launch to them.
+//
+//   k_jive2_coop<F, 16>     Jive::compress 2-1 / Sponge::merge   src/<f>/anemoi_2_1/hasher.rs:86-103    4 items per wavefront
+//   k_jive2_coop<F, 64>     the same, one item per wavefront (rounds 1-2's form; A/B and parity only)
+//   k_jive4_coop<F, K>      Jive::compress(_k) 4-3               src/<f>/anemoi_4_3/hasher.rs:148-179   2 states per wavefront
+//   k_permutation_coop      Anemoi::permutation                  src/traits.rs:370-378
+//   k_merkle_climb_coop     authentication-path verification     (depth x merge)
+//   k_sponge_coop           Sponge::hash / hash_field            anemoi_2_1/hasher.rs:18-85, anemoi_4_3/hasher.rs:19-129
+//
+// All of them are built on coop_permutation (one column (x, y) per row; the 4-3 linear layer couples two rows) and
+// coop_flystel (the S-box with its sliding-window exponentiation, table in LDS).  Same round function and the same
+// bound bookkeeping as the lane-private kernels of anemoi_kernels.h; every kernel is forced for every size and field
+// against the oracle by tests/test_gpu_parity.py.
+#pragma once
+// included from anemoi_kernels.h (after kBlock, PermConsts and uniform_word)
+
+namespace anemoi {
+
+// ---- wave-cooperative Jive 2-to-1 compression (coop29.h) ----------------------------------------------
+// Latency path: small batches (the top levels of a Merkle tree, a single Jive::compress / Sponge::merge call).
+// Same round function and the same bound bookkeeping as the lane-private kernels; the window table (F::kCoopWin
+// bits, one word per lane and entry) sits in LDS.  Two layouts of the same arithmetic:
+//   LPR = 16  FOUR items per wavefront, one per 16-lane DPP row; everything row-local (a_i and the quotient digit
+//             by DPP row broadcast, the digit computed on the VALU).  The shipped latency kernel: one BLS12-381
+//             compression 2.98 ms, Jubjub 1.44 ms, flat up to 4 096 items (one wavefront per SIMD).
+//   LPR = 64  ONE item per wavefront, a_i and the quotient digit through v_readlane -> SGPR -> scalar ALU (rounds
+//             1-2's latency kernel): 4.10 / 1.96 ms -- the scalar round trip costs more than the VALU digit, and a
+//             wavefront carries a quarter of the items.  Kept selectable (ANEMOI_COOP_MAX) for A/B and parity.
+// Cut-offs from the per-size sweep (tools/sweep_coop.py, profiles/r03/coop_kernel_sweep.txt): the row-cooperative
+// kernel wins up to 8 192 items on both limb counts (Jubjub 2.25 vs 2.41 ms, BLS12-381 4.82 vs 7.29 ms at 8 192;
+// lane-private from 16 384: 2.41 vs 3.98, 7.27 vs 8.81).  The knobs are read at every call; the parity tests force
+// each kernel for every size.
+inline size_t coop_max_items(int) {
+  if (const char* e = getenv("ANEMOI_COOP_MAX")) return size_t(strtoull(e, nullptr, 10));
+  return 0;
+}
+inline size_t coop4_max_items(int) {
+  if (const char* e = getenv("ANEMOI_COOP4_MAX")) return size_t(strtoull(e, nullptr, 10));
+  return 8192;
+}
+// Anemoi-4-3: batches up to this many states take the row-cooperative kernel k_jive4_coop (two states per wavefront),
+// larger ones the lane-pair kernel; ANEMOI_COOP43_MAX overrides (0 = never)
+// Sponge batches (whole messages in one launch) of up to this many messages take k_sponge_coop;
+// ANEMOI_COOP_SPONGE_MAX overrides (0 = never)
+// (profiles/r03/coop_kernel_sweep.txt, 1 KB messages: Jubjub 2-1 49.1 vs 86.5 ms up to 1 024 messages, 51.6 vs 86.7 at
+// 4 096, 134.6 vs 86.8 at 16 384; BN-254 4-3 12.0 vs 22.4 ms, 18.3 vs 22.4 at 4 096, 61.8 vs 22.9 at 16 384)
+inline size_t coop_sponge_max_items(int, int) {
+  if (const char* e = getenv("ANEMOI_COOP_SPONGE_MAX")) return size_t(strtoull(e, nullptr, 10));
+  return 4096;
+}
+// (sweep in profiles/r03/coop_kernel_sweep.txt: BN-254 1.17 vs 1.64 ms at 2 048 states, 1.68 vs 1.66 at 4 096;
+// BLS12-381 3.35 vs 4.84 ms at 4 096, 5.95 vs 4.85 at 8 192)
+inline size_t coop43_max_items(int limbs29) {
+  if (const char* e = getenv("ANEMOI_COOP43_MAX")) return size_t(strtoull(e, nullptr, 10));
+  return limbs29 >= 14 ? 4096 : 2048;
+}
+
+// Flystel S-box (src/traits.rs:326-358) on the cooperative arithmetic: x -= g y^2 ; y -= x^(1/alpha) ; x += g y^2 + delta,
+// the exponentiation by a sliding window of F::kCoopWin bits over odd powers held in LDS (one word per lane and entry)
+template <class F, class C>
+__device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typename C::K& k, uint32_t* tab,
+                                             const PermConsts& pc) {
+  constexpr int E = 1 << (F::kCoopWin - 1);
+  const uint32_t lane = threadIdx.x;
+  uint32_t t = C::mul(y, y, k.pl);
+  x = C::sub(x, C::mul_g(t, k), k.kpl);
+  {
+    const uint32_t x2 = C::mul(x, x, k.pl);
+    uint32_t pw = x;
+    tab[lane] = pw;
+#pragma nounroll
+    for (int i = 1; i < E; i++) {
+      pw = C::mul(pw, x2, k.pl);
+      tab[i * kBlock + lane] = pw;
+    }
+    uint32_t acc = tab[pc.first5 * kBlock + lane], tmp = acc;
+#pragma nounroll
+    for (int s = 0; s < pc.steps5; s++) {
+      const uint32_t word = uniform_word(pc.sched5, s);
+      const int nsq = word & 0xff, idx = word >> 8;
+      if (idx == 253) {  // leading-run doubling, see sliding_window() in tools/gen_params.py
+        tmp = acc;
+        continue;
+      }
+      // the step's table operand is read from LDS BEFORE its squarings (a lone wavefront would otherwise sit out the
+      // LDS latency in front of every multiplication)
+      const uint32_t opnd = idx < 253 ? tab[idx * kBlock + lane] : 0u;
+#pragma nounroll
+      for (int q = 0; q < nsq; q++) acc = C::mul(acc, acc, k.pl);
+      if (idx == 254) acc = C::mul(acc, tmp, k.pl);
+      else if (idx != 255) acc = C::mul(acc, opnd, k.pl);
+    }
+    t = acc;
+  }
+  y = C::sub(y, t, k.kpl);
+  t = C::mul(y, y, k.pl);
+  x = C::add(C::add(x, C::mul_g(t, k)), k.delta);
+}
+
+// Anemoi::permutation (src/traits.rs:370-378) on the cooperative arithmetic, for one column (x, y) per element row.
+//   W = 2: the state is (x, y); mds_layer arm NUM_COLUMNS = 1 (src/traits.rs:136-142).
+//   W = 4: a state's two columns sit on two adjacent 16-lane rows (row 2s holds (x0, y0) = (state[0], state[2]),
+//          row 2s + 1 holds (x1, y1)) -- the lane-pair idea of anemoi_perm.h one level up.  The two S-boxes of a
+//          round run side by side; only the linear layer (arm 2, src/traits.rs:143-157) couples the rows, through
+//          five cross-row exchanges per round.  Every cross-lane operation (the row exchange, the DPP carries
+//          inside add / mul_g) is executed by ALL lanes and the result selected afterwards: under divergent control
+//          flow a ds_bpermute reads nothing from inactive lanes.
+template <class F, class C, int W>
+__device__ __forceinline__ void coop_permutation(uint32_t& x, uint32_t& y, const typename C::K& k, uint32_t* tab,
+                                                 const PermConsts& pc) {
+  constexpr int NL = C::NL, R = W == 2 ? F::kRounds21 : F::kRounds43;
+  const uint32_t j = C::limb(), col = W == 4 ? ((threadIdx.x / 16) & 1) : 0;
+  const bool odd = col != 0;
+  auto other = [](uint32_t v) { return (uint32_t)__shfl_xor((int)v, 16); };   // the same limb of the partner row
+  // round constants: the NEXT round's pair is fetched while this round's S-box runs (vector loads, one limb per lane)
+  auto konst = [&](const uint32_t* tabk, int r) { return j < NL ? tabk[(r * (W / 2) + int(col)) * NL + j] : 0u; };
+  uint32_t kc = konst(pc.coop_c, 0), kd = konst(pc.coop_d, 0);
+#pragma nounroll
+  for (int r = 0; r <= R; r++) {
+    if (r < R) {  // ark_layer (src/traits.rs:111-125): C[r * c + col], D[r * c + col]
+      x = C::add(x, kc);
+      y = C::add(y, kd);
+      if (r + 1 < R) kc = konst(pc.coop_c, r + 1), kd = konst(pc.coop_d, r + 1);
+    }
+    if constexpr (W == 2) {
+      y = C::add(y, x);
+      x = C::add(x, y);
+    } else {
+      // s0 += g s1 ; s1 += g s0 ; s3 += g s2 ; s2 += g s3 ; swap(s2, s3) ; s2 += s0 ; s3 += s1 ; s0 += s2 ; s1 += s3
+      uint32_t ox = other(x), oy = other(y);
+      uint32_t p = odd ? oy : ox;               // even: s1 (the odd row's x); odd: s2 (the even row's y)
+      uint32_t t = C::mul_g(p, k);
+      uint32_t sx = C::add(x, t), sy = C::add(y, t);
+      x = odd ? x : sx;                         // even: s0 += g s1
+      y = odd ? sy : y;                         // odd:  s3 += g s2
+      ox = other(x), oy = other(y);
+      p = odd ? ox : oy;                        // odd: the updated s0; even: the updated s3
+      t = C::mul_g(p, k);
+      sx = C::add(x, t), sy = C::add(y, t);
+      x = odd ? sx : x;                         // odd:  s1 += g s0
+      y = odd ? y : sy;                         // even: s2 += g s3
+      y = other(y);                             // swap(s2, s3)
+      y = C::add(y, x);                         // s2 += s0 ; s3 += s1
+      x = C::add(x, y);                         // s0 += s2 ; s1 += s3
+    }
+    x = C::settle(x, k);  // back below 2p
+    y = C::settle(y, k);
+    if (r == R) break;  // permutation = R rounds + a final mds_layer
+    coop_flystel<F, C>(x, y, k, tab, pc);  // sbox_layer (src/traits.rs:326-358)
+  }
+}
+
+template <int FIELD, int LPR>
+__global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                       size_t n, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using C = Coop29<F, LPR>;
+  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = kBlock / LPR;
+  __shared__ uint32_t tab[E * kBlock];
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR;
+  const typename C::K k = C::load_consts();
+  const size_t groups = (n + PER - 1) / PER;   // a wavefront works on PER consecutive items
+  for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const size_t want = g * PER + row;
+    const bool live = want < n;
+    const size_t item = live ? want : n - 1;   // rows beyond the batch redo the last item (all rows run the same code)
+    const uint32_t w0 = j < NABI ? in[(item * 2 + 0) * NABI + j] : 0u;
+    const uint32_t w1 = j < NABI ? in[(item * 2 + 1) * NABI + j] : 0u;
+    const uint32_t e0 = C::from_abi(w0, k), e1 = C::from_abi(w1, k);
+    uint32_t x = e0, y = e1;
+    coop_permutation<F, C, 2>(x, y, k, tab, pc);
+    // Jive feed-forward: state[0] + state[1] + elems[0] + elems[1] (anemoi_2_1/hasher.rs:102)
+    const uint32_t s = C::add(C::add(x, y), C::add(e0, e1));
+    const uint32_t o = C::to_abi(s, k);
+    if (live && j < NABI) out[item * NABI + j] = o;
+  }
+}
+
+// Anemoi-4-3 Jive on the row-cooperative arithmetic: TWO states per wavefront (coop_permutation<.., 4>).
+// K = 2: out[i] = e_i + e_{i+2} + s_i + s_{i+2} is row-local; K = 4: the two rows' sums are added
+// (anemoi_4_3/hasher.rs:148-179).
+template <int FIELD, int K>
+__global__ __launch_bounds__(kBlock) void k_jive4_coop(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                       size_t n, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using C = Coop29<F, 16>;
+  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = 2;
+  __shared__ uint32_t tab[E * kBlock];
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16, col = row & 1;
+  const bool odd = col != 0;
+  const typename C::K k = C::load_consts();
+  const size_t groups = (n + PER - 1) / PER;
+  for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const size_t want = g * PER + row / 2;
+    const bool live = want < n;
+    const size_t item = live ? want : n - 1;
+    const uint32_t w0 = j < NABI ? in[(item * 4 + col) * NABI + j] : 0u;
+    const uint32_t w1 = j < NABI ? in[(item * 4 + 2 + col) * NABI + j] : 0u;
+    const uint32_t e0 = C::from_abi(w0, k), e1 = C::from_abi(w1, k);
+    uint32_t x = e0, y = e1;
+    coop_permutation<F, C, 4>(x, y, k, tab, pc);
+    uint32_t s = C::add(C::add(x, y), C::add(e0, e1));   // this column's share of the Jive sum
+    const uint32_t os = (uint32_t)__shfl_xor((int)s, 16);
+    if (K == 4) s = C::add(s, os);
+    const uint32_t o = C::to_abi(s, k);
+    if (K == 2) {
+      if (live && j < NABI) out[(item * 2 + col) * NABI + j] = o;
+    } else {
+      if (live && !odd && j < NABI) out[item * NABI + j] = o;
+    }
+  }
+}
+
+// Anemoi::permutation (src/traits.rs:370-378), in place, on the row-cooperative arithmetic: four states per wavefront
+// (W = 2) or two (W = 4) -- the latency form of k_permutation / k_permutation_pair for small batches.
+template <int FIELD, int W>
+__global__ __launch_bounds__(kBlock) void k_permutation_coop(uint32_t* __restrict__ states, size_t n, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using C = Coop29<F, 16>;
+  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? 4 : 2;
+  __shared__ uint32_t tab[E * kBlock];
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16, col = W == 4 ? (row & 1) : 0;
+  const typename C::K k = C::load_consts();
+  const size_t groups = (n + PER - 1) / PER;
+  for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const size_t want = g * PER + (W == 2 ? row : row / 2);
+    const bool live = want < n;
+    const size_t item = live ? want : n - 1;
+    uint32_t* sx = states + (item * W + col) * NABI;          // state[col]
+    uint32_t* sy = states + (item * W + W / 2 + col) * NABI;  // state[c + col]
+    uint32_t x = C::from_abi(j < NABI ? sx[j] : 0u, k), y = C::from_abi(j < NABI ? sy[j] : 0u, k);
+    coop_permutation<F, C, W>(x, y, k, tab, pc);
+    const uint32_t ox = C::to_abi(x, k), oy = C::to_abi(y, k);
+    if (live && j < NABI) {
+      sx[j] = ox;
+      sy[j] = oy;
+    }
+  }
+}
+
+// Authentication-path verification (k_merkle_climb) on the row-cooperative arithmetic: four paths per wavefront, each
+// climbing its `depth` merges one after the other at the cooperative latency -- for a handful of paths.
+template <int FIELD>
+__global__ __launch_bounds__(kBlock) void k_merkle_climb_coop(const uint32_t* __restrict__ leaves,
+                                                              const uint64_t* __restrict__ index,
+                                                              const uint32_t* __restrict__ paths, unsigned depth, size_t n,
+                                                              uint32_t* __restrict__ out, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using C = Coop29<F, 16>;
+  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = 4;
+  __shared__ uint32_t tab[E * kBlock];
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16;
+  const typename C::K k = C::load_consts();
+  const size_t groups = (n + PER - 1) / PER;
+  for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const size_t want = g * PER + row;
+    const bool live = want < n;
+    const size_t item = live ? want : n - 1;
+    const uint64_t idx = index[item];
+    uint32_t cur = C::from_abi(j < NABI ? leaves[item * NABI + j] : 0u, k);
+#pragma nounroll
+    for (unsigned l = 0; l < depth; l++) {
+      const uint32_t sib = C::from_abi(j < NABI ? paths[(item * depth + l) * NABI + j] : 0u, k);
+      const bool right = (idx >> l) & 1;   // this node is the right child: state = [sibling, node]
+      uint32_t x = right ? sib : cur, y = right ? cur : sib;
+      const uint32_t sum = C::add(cur, sib);
+      coop_permutation<F, C, 2>(x, y, k, tab, pc);
+      cur = C::settle(C::add(C::add(x, y), sum), k);   // Jive feed-forward, back below 2p for the next level
+    }
+    const uint32_t o = C::to_abi(cur, k);
+    if (live && j < NABI) out[item * NABI + j] = o;
+  }
+}
+
+// Sponge::hash / hash_field (anemoi_2_1/hasher.rs:18-85, anemoi_4_3/hasher.rs:19-129) on the row-cooperative
+// arithmetic, for SMALL batches of messages of equal length: four messages per wavefront (W = 2), two (W = 4).  The
+// same unified rule as k_sponge: absorb into state[pos]; permute when pos == RATE or at the last element; when
+// num % RATE != 0 a final element 1 is absorbed; digest = state[0].  W = 4: state[0], state[1] = x of the even / odd
+// row, state[2] = y of the even row; both rows of a pair decode the same element and the row that owns state[pos]
+// keeps the sum.  A byte message's element e is its chunk e (F::kChunk bytes, little-endian, a 0x01 byte appended to
+// a short last chunk, hasher.rs:36-57): lane j cuts its 29-bit limb out of the five bytes that hold it.
+template <int FIELD, int W, bool BYTES>
+__global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__ src, size_t per_msg, size_t n,
+                                                        uint32_t* __restrict__ out, PermConsts pc) {
+  using F = FieldC<FIELD>;
+  using C = Coop29<F, 16>;
+  constexpr int NL = C::NL, NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? 4 : 2, RATE = W - 1;
+  __shared__ uint32_t tab[E * kBlock];
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16, col = W == 4 ? (row & 1) : 0;
+  const bool odd = col != 0;
+  const typename C::K k = C::load_consts();
+  const size_t num = BYTES ? (per_msg + F::kChunk - 1) / F::kChunk : per_msg;
+  const size_t total = num + (num % RATE == 0 ? 0 : 1);
+  const size_t groups = (n + PER - 1) / PER;
+  for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const size_t want = g * PER + (W == 2 ? row : row / 2);
+    const bool live = want < n;
+    const size_t item = live ? want : n - 1;
+    const uint8_t* msg = (const uint8_t*)src + (BYTES ? item * per_msg : item * per_msg * NABI * 4);
+    uint32_t x = 0, y = 0;
+    int pos = 0;
+#pragma nounroll
+    for (size_t e = 0; e < total; e++) {
+      uint32_t el;
+      if (e >= num) {
+        el = k.one;
+      } else if (BYTES) {
+        const size_t c0 = e * F::kChunk, left = per_msg - c0;
+        const int clen = left < size_t(F::kChunk) ? int(left) : F::kChunk;
+        const int bit = 29 * int(j), b0 = bit >> 3, sh = bit & 7;
+        uint64_t v = 0;
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+          const int at = b0 + t;
+          uint32_t byte = 0;
+          if (j < NL && at < F::kChunk) {
+            if (at < clen) byte = msg[c0 + at];
+            else if (at == clen) byte = 1;   // only reachable when clen < kChunk
+          }
+          v |= uint64_t(byte) << (8 * t);
+        }
+        const uint32_t limb = j < NL ? uint32_t(v >> sh) & C::MASK : 0u;
+        el = C::mul(limb, k.rr, k.pl);            // plain integer < p -> Montgomery form
+      } else {
+        const uint32_t w = j < NABI ? ((const uint32_t*)msg)[e * NABI + j] : 0u;
+        el = C::from_abi(w, k);
+      }
+      // pos is wave-uniform (every message has the same length)
+      const uint32_t sx = C::add(x, el), sy = C::add(y, el);
+      if (W == 2) {
+        x = sx;
+      } else {
+        if (pos < 2) x = (odd == (pos == 1)) ? sx : x;
+        else y = odd ? y : sy;
+      }
+      pos++;
+      if (pos == RATE || e == total - 1) {
+        coop_permutation<F, C, W>(x, y, k, tab, pc);
+        pos = 0;
+      }
+    }
+    const uint32_t o = C::to_abi(x, k);   // digest = state[0]
+    if (live && !odd && j < NABI) out[item * NABI + j] = o;
+  }
+}
+
+}  // namespace anemoi
