@@ -66,6 +66,8 @@ _SIGS = {
     "anemoi_num_rounds": ([_int, _int], _int),
     "anemoi_init": ([_int, _int, _int], _int),
     "anemoi_release": ([_int], _int),
+    "anemoi_set_option": ([ctypes.c_char_p, ctypes.c_longlong], _int),
+    "anemoi_get_option": ([ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)], _int),
     "anemoi_permutation_batch": ([_int, _int, _u64p, _sz, _int], _int),
     "anemoi_sbox_layer_batch": ([_int, _int, _u64p, _sz, _int], _int),
     "anemoi_sbox_layer_dev": ([_int, _int, _vp, _sz, _vp], _int),
@@ -141,6 +143,47 @@ def release(device=ALL_DEVICES):
     rc = lib.anemoi_release(device)
     if rc != 0:
         raise AnemoiError(rc, lib.anemoi_last_error().decode())
+
+
+OPTIONS = ("coop_max", "coop2d_max", "coop4_max", "coop43_max", "coop_sponge_max", "coop_climb_max",
+           "merkle_subtrees_log2", "virtual_devices", "host_staging", "chunk_target_bytes", "test_quantum",
+           "sponge_segment_bytes")
+AUTO = -1
+
+
+def set_option(name, value):
+    """anemoi_set_option: value AUTO (-1) / None restores the automatic default; host_staging also takes
+    "pinned" / "direct".  Options are process-wide and affect calls that start afterwards."""
+    if value is None:
+        value = AUTO
+    if name == "host_staging" and isinstance(value, str):
+        value = {"pinned": 1, "direct": 0}[value]
+    _check(lib.anemoi_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = ctypes.c_longlong(0)
+    _check(lib.anemoi_get_option(name.encode(), ctypes.byref(v)))
+    return v.value
+
+
+class options:
+    """Context manager: `with options(coop4_max=0, virtual_devices=8): ...` sets the options and restores the
+    previous values on exit (what the tests used to do through os.environ)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def field_id(field):

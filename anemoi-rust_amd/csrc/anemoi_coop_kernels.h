@@ -17,7 +17,14 @@
 
 namespace anemoi {
 
-// ---- wave-cooperative Jive 2-to-1 compression (coop29.h) ----------------------------------------------
+// Lanes per item -> the cooperative arithmetic: 64 / 16 = the digit-serial scan of coop29.h (one item per wavefront /
+// one per DPP row), 32 = the two-row fold product of coop2d.h (two items per wavefront, the lowest latency)
+template <class F, int LPI>
+struct CoopArith { using type = Coop29<F, LPI>; };
+template <class F>
+struct CoopArith<F, 32> { using type = Coop2d<F>; };
+
+// ---- wave-cooperative Jive 2-to-1 compression (coop29.h, coop2d.h) ------------------------------------
 // Latency path: small batches (the top levels of a Merkle tree, a single Jive::compress / Sponge::merge call).
 // Same round function and the same bound bookkeeping as the lane-private kernels; the window table (F::kCoopWin
 // bits, one word per lane and entry) sits in LDS.  Two layouts of the same arithmetic:
@@ -27,34 +34,30 @@ namespace anemoi {
 //   LPR = 64  ONE item per wavefront, a_i and the quotient digit through v_readlane -> SGPR -> scalar ALU (rounds
 //             1-2's latency kernel): 4.10 / 1.96 ms -- the scalar round trip costs more than the VALU digit, and a
 //             wavefront carries a quarter of the items.  Kept selectable (ANEMOI_COOP_MAX) for A/B and parity.
-// Cut-offs from the per-size sweep (tools/sweep_coop.py, profiles/r03/coop_kernel_sweep.txt): the row-cooperative
+// Cut-offs from the per-size sweeps (tools/sweep_coop.py, profiles/r03/coop_kernel_sweep.txt): the row-cooperative
 // kernel wins up to 8 192 items on both limb counts (Jubjub 2.25 vs 2.41 ms, BLS12-381 4.82 vs 7.29 ms at 8 192;
-// lane-private from 16 384: 2.41 vs 3.98, 7.27 vs 8.81).  The knobs are read at every call; the parity tests force
-// each kernel for every size.
-inline size_t coop_max_items(int) {
-  if (const char* e = getenv("ANEMOI_COOP_MAX")) return size_t(strtoull(e, nullptr, 10));
-  return 0;
-}
-inline size_t coop4_max_items(int) {
-  if (const char* e = getenv("ANEMOI_COOP4_MAX")) return size_t(strtoull(e, nullptr, 10));
-  return 8192;
-}
+// lane-private from 16 384: 2.41 vs 3.98, 7.27 vs 8.81) -- that is two wavefronts of four items on each of the
+// MI355X's 1 024 SIMDs, and the automatic cut-offs are stated that way (`simds` = 4 x the device's CU count, so a
+// partitioned or smaller device scales them).  Each is an option (options.h: read from the environment ONCE, changed
+// through anemoi_set_option; the parity tests force each kernel for every size that way).
+inline size_t coop_max_items() { return size_t(opt::get_or(opt::kCoopMax, 0)); }
+// Anemoi-2-1 batches up to this size take the two-row fold kernels (coop2d.h, two items per wavefront): one
+// wavefront per SIMD -- beyond that the second wavefront of a SIMD costs more than the scan kernel's extra instructions
+inline size_t coop2d_max_items(int simds) { return size_t(opt::get_or(opt::kCoop2dMax, 2ll * simds)); }
+inline size_t coop4_max_items(int simds) { return size_t(opt::get_or(opt::kCoop4Max, 8ll * simds)); }
 // Anemoi-4-3: batches up to this many states take the row-cooperative kernel k_jive4_coop (two states per wavefront),
-// larger ones the lane-pair kernel; ANEMOI_COOP43_MAX overrides (0 = never)
-// Sponge batches (whole messages in one launch) of up to this many messages take k_sponge_coop;
-// ANEMOI_COOP_SPONGE_MAX overrides (0 = never)
-// (profiles/r03/coop_kernel_sweep.txt, 1 KB messages: Jubjub 2-1 49.1 vs 86.5 ms up to 1 024 messages, 51.6 vs 86.7 at
-// 4 096, 134.6 vs 86.8 at 16 384; BN-254 4-3 12.0 vs 22.4 ms, 18.3 vs 22.4 at 4 096, 61.8 vs 22.9 at 16 384)
-inline size_t coop_sponge_max_items(int, int) {
-  if (const char* e = getenv("ANEMOI_COOP_SPONGE_MAX")) return size_t(strtoull(e, nullptr, 10));
-  return 4096;
+// larger ones the lane-pair kernel (sweep: BN-254 1.17 vs 1.64 ms at 2 048 states, 1.68 vs 1.66 at 4 096; BLS12-381
+// 3.35 vs 4.84 ms at 4 096, 5.95 vs 4.85 at 8 192): one wavefront per SIMD on 9 limbs, two on 14
+inline size_t coop43_max_items(int simds, int limbs29) {
+  return size_t(opt::get_or(opt::kCoop43Max, (limbs29 >= 14 ? 4ll : 2ll) * simds));
 }
-// (sweep in profiles/r03/coop_kernel_sweep.txt: BN-254 1.17 vs 1.64 ms at 2 048 states, 1.68 vs 1.66 at 4 096;
-// BLS12-381 3.35 vs 4.84 ms at 4 096, 5.95 vs 4.85 at 8 192)
-inline size_t coop43_max_items(int limbs29) {
-  if (const char* e = getenv("ANEMOI_COOP43_MAX")) return size_t(strtoull(e, nullptr, 10));
-  return limbs29 >= 14 ? 4096 : 2048;
-}
+// Sponge batches (whole messages of one length in one launch) of up to this many messages take k_sponge_coop
+// (1 KB messages: Jubjub 2-1 49.1 vs 86.5 ms up to 1 024 messages, 51.6 vs 86.7 at 4 096, 134.6 vs 86.8 at 16 384;
+// BN-254 4-3 12.0 vs 22.4 ms, 18.3 vs 22.4 at 4 096, 61.8 vs 22.9 at 16 384)
+inline size_t coop_sponge_max_items(int simds) { return size_t(opt::get_or(opt::kCoopSpongeMax, 4ll * simds)); }
+// Batches of authentication paths up to this size climb on k_merkle_climb_coop (four paths per wavefront); its own
+// knob (round 3 borrowed the sponge's, so that one switched two kernels)
+inline size_t coop_climb_max_items(int simds) { return size_t(opt::get_or(opt::kCoopClimbMax, 4ll * simds)); }
 
 // Flystel S-box (src/traits.rs:326-358) on the cooperative arithmetic: x -= g y^2 ; y -= x^(1/alpha) ; x += g y^2 + delta,
 // the exponentiation by a sliding window of F::kCoopWin bits over odd powers held in LDS (one word per lane and entry)
@@ -63,15 +66,15 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typ
                                              const PermConsts& pc) {
   constexpr int E = 1 << (F::kCoopWin - 1);
   const uint32_t lane = threadIdx.x;
-  uint32_t t = C::mul(y, y, k.pl);
-  x = C::sub(x, C::mul_g(t, k), k.kpl);
+  uint32_t t = C::mul(y, y, k);
+  x = C::sub(x, C::mul_g(t, k), k);
   {
-    const uint32_t x2 = C::mul(x, x, k.pl);
+    const uint32_t x2 = C::mul(x, x, k);
     uint32_t pw = x;
     tab[lane] = pw;
 #pragma nounroll
     for (int i = 1; i < E; i++) {
-      pw = C::mul(pw, x2, k.pl);
+      pw = C::mul(pw, x2, k);
       tab[i * kBlock + lane] = pw;
     }
     uint32_t acc = tab[pc.first5 * kBlock + lane], tmp = acc;
@@ -87,16 +90,28 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typ
       // LDS latency in front of every multiplication)
       const uint32_t opnd = idx < 253 ? tab[idx * kBlock + lane] : 0u;
 #pragma nounroll
-      for (int q = 0; q < nsq; q++) acc = C::mul(acc, acc, k.pl);
-      if (idx == 254) acc = C::mul(acc, tmp, k.pl);
-      else if (idx != 255) acc = C::mul(acc, opnd, k.pl);
+      for (int q = 0; q < nsq; q++) acc = C::mul(acc, acc, k);
+      if (idx == 254) acc = C::mul(acc, tmp, k);
+      else if (idx != 255) acc = C::mul(acc, opnd, k);
     }
     t = acc;
   }
-  y = C::sub(y, t, k.kpl);
-  t = C::mul(y, y, k.pl);
+  y = C::sub(y, t, k);
+  t = C::mul(y, y, k);
   x = C::add(C::add(x, C::mul_g(t, k)), k.delta);
 }
+
+// the instance's round constants in the limb layout of the arithmetic (PermConsts carries both)
+template <class C>
+struct CoopArk {
+  __device__ static __forceinline__ const uint32_t* c(const PermConsts& pc) { return pc.coop_c; }
+  __device__ static __forceinline__ const uint32_t* d(const PermConsts& pc) { return pc.coop_d; }
+};
+template <class F>
+struct CoopArk<Coop2d<F>> {
+  __device__ static __forceinline__ const uint32_t* c(const PermConsts& pc) { return pc.fold_c; }
+  __device__ static __forceinline__ const uint32_t* d(const PermConsts& pc) { return pc.fold_d; }
+};
 
 // Anemoi::permutation (src/traits.rs:370-378) on the cooperative arithmetic, for one column (x, y) per element row.
 //   W = 2: the state is (x, y); mds_layer arm NUM_COLUMNS = 1 (src/traits.rs:136-142).
@@ -115,13 +130,15 @@ __device__ __forceinline__ void coop_permutation(uint32_t& x, uint32_t& y, const
   auto other = [](uint32_t v) { return (uint32_t)__shfl_xor((int)v, 16); };   // the same limb of the partner row
   // round constants: the NEXT round's pair is fetched while this round's S-box runs (vector loads, one limb per lane)
   auto konst = [&](const uint32_t* tabk, int r) { return j < NL ? tabk[(r * (W / 2) + int(col)) * NL + j] : 0u; };
-  uint32_t kc = konst(pc.coop_c, 0), kd = konst(pc.coop_d, 0);
+  const uint32_t* const ark_c = CoopArk<C>::c(pc);
+  const uint32_t* const ark_d = CoopArk<C>::d(pc);
+  uint32_t kc = konst(ark_c, 0), kd = konst(ark_d, 0);
 #pragma nounroll
   for (int r = 0; r <= R; r++) {
     if (r < R) {  // ark_layer (src/traits.rs:111-125): C[r * c + col], D[r * c + col]
       x = C::add(x, kc);
       y = C::add(y, kd);
-      if (r + 1 < R) kc = konst(pc.coop_c, r + 1), kd = konst(pc.coop_d, r + 1);
+      if (r + 1 < R) kc = konst(ark_c, r + 1), kd = konst(ark_d, r + 1);
     }
     if constexpr (W == 2) {
       y = C::add(y, x);
@@ -155,7 +172,7 @@ template <int FIELD, int LPR>
 __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                        size_t n, PermConsts pc) {
   using F = FieldC<FIELD>;
-  using C = Coop29<F, LPR>;
+  using C = typename CoopArith<F, LPR>::type;
   constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = kBlock / LPR;
   __shared__ uint32_t tab[E * kBlock];
   const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR;
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
     // Jive feed-forward: state[0] + state[1] + elems[0] + elems[1] (anemoi_2_1/hasher.rs:102)
     const uint32_t s = C::add(C::add(x, y), C::add(e0, e1));
     const uint32_t o = C::to_abi(s, k);
-    if (live && j < NABI) out[item * NABI + j] = o;
+    if (live && C::writer() && j < NABI) out[item * NABI + j] = o;
   }
 }
 
@@ -214,13 +231,14 @@ __global__ __launch_bounds__(kBlock) void k_jive4_coop(const uint32_t* __restric
 
 // Anemoi::permutation (src/traits.rs:370-378), in place, on the row-cooperative arithmetic: four states per wavefront
 // (W = 2) or two (W = 4) -- the latency form of k_permutation / k_permutation_pair for small batches.
-template <int FIELD, int W>
+template <int FIELD, int W, int LPR = 16>
 __global__ __launch_bounds__(kBlock) void k_permutation_coop(uint32_t* __restrict__ states, size_t n, PermConsts pc) {
   using F = FieldC<FIELD>;
-  using C = Coop29<F, 16>;
-  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? 4 : 2;
+  using C = typename CoopArith<F, LPR>::type;
+  static_assert(LPR == 16 || W == 2, "the 4-3 form puts a state's two columns on two adjacent 16-lane rows");
+  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? kBlock / LPR : 2;
   __shared__ uint32_t tab[E * kBlock];
-  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16, col = W == 4 ? (row & 1) : 0;
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR, col = W == 4 ? (row & 1) : 0;
   const typename C::K k = C::load_consts();
   const size_t groups = (n + PER - 1) / PER;
   for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_permutation_coop(uint32_t* __restric
     uint32_t x = C::from_abi(j < NABI ? sx[j] : 0u, k), y = C::from_abi(j < NABI ? sy[j] : 0u, k);
     coop_permutation<F, C, W>(x, y, k, tab, pc);
     const uint32_t ox = C::to_abi(x, k), oy = C::to_abi(y, k);
-    if (live && j < NABI) {
+    if (live && C::writer() && j < NABI) {
       sx[j] = ox;
       sy[j] = oy;
     }
@@ -241,16 +259,16 @@ __global__ __launch_bounds__(kBlock) void k_permutation_coop(uint32_t* __restric
 
 // Authentication-path verification (k_merkle_climb) on the row-cooperative arithmetic: four paths per wavefront, each
 // climbing its `depth` merges one after the other at the cooperative latency -- for a handful of paths.
-template <int FIELD>
+template <int FIELD, int LPR = 16>
 __global__ __launch_bounds__(kBlock) void k_merkle_climb_coop(const uint32_t* __restrict__ leaves,
                                                               const uint64_t* __restrict__ index,
                                                               const uint32_t* __restrict__ paths, unsigned depth, size_t n,
                                                               uint32_t* __restrict__ out, PermConsts pc) {
   using F = FieldC<FIELD>;
-  using C = Coop29<F, 16>;
-  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = 4;
+  using C = typename CoopArith<F, LPR>::type;
+  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = kBlock / LPR;
   __shared__ uint32_t tab[E * kBlock];
-  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16;
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR;
   const typename C::K k = C::load_consts();
   const size_t groups = (n + PER - 1) / PER;
   for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_merkle_climb_coop(const uint32_t* __
       cur = C::settle(C::add(C::add(x, y), sum), k);   // Jive feed-forward, back below 2p for the next level
     }
     const uint32_t o = C::to_abi(cur, k);
-    if (live && j < NABI) out[item * NABI + j] = o;
+    if (live && C::writer() && j < NABI) out[item * NABI + j] = o;
   }
 }
 
@@ -280,14 +298,15 @@ __global__ __launch_bounds__(kBlock) void k_merkle_climb_coop(const uint32_t* __
 // row, state[2] = y of the even row; both rows of a pair decode the same element and the row that owns state[pos]
 // keeps the sum.  A byte message's element e is its chunk e (F::kChunk bytes, little-endian, a 0x01 byte appended to
 // a short last chunk, hasher.rs:36-57): lane j cuts its 29-bit limb out of the five bytes that hold it.
-template <int FIELD, int W, bool BYTES>
+template <int FIELD, int W, bool BYTES, int LPR = 16>
 __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__ src, size_t per_msg, size_t n,
                                                         uint32_t* __restrict__ out, PermConsts pc) {
   using F = FieldC<FIELD>;
-  using C = Coop29<F, 16>;
-  constexpr int NL = C::NL, NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? 4 : 2, RATE = W - 1;
+  using C = typename CoopArith<F, LPR>::type;
+  static_assert(LPR == 16 || W == 2, "the 4-3 form puts a state's two columns on two adjacent 16-lane rows");
+  constexpr int NL = C::NL, NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? kBlock / LPR : 2, RATE = W - 1;
   __shared__ uint32_t tab[E * kBlock];
-  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16, col = W == 4 ? (row & 1) : 0;
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR, col = W == 4 ? (row & 1) : 0;
   const bool odd = col != 0;
   const typename C::K k = C::load_consts();
   const size_t num = BYTES ? (per_msg + F::kChunk - 1) / F::kChunk : per_msg;
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
       } else if (BYTES) {
         const size_t c0 = e * F::kChunk, left = per_msg - c0;
         const int clen = left < size_t(F::kChunk) ? int(left) : F::kChunk;
-        const int bit = 29 * int(j), b0 = bit >> 3, sh = bit & 7;
+        const int bit = C::W * int(j), b0 = bit >> 3, sh = bit & 7;
         uint64_t v = 0;
 #pragma unroll
         for (int t = 0; t < 5; t++) {
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
           v |= uint64_t(byte) << (8 * t);
         }
         const uint32_t limb = j < NL ? uint32_t(v >> sh) & C::MASK : 0u;
-        el = C::mul(limb, k.rr, k.pl);            // plain integer < p -> Montgomery form
+        el = C::to_mont(limb, k);                 // plain integer < p -> Montgomery form
       } else {
         const uint32_t w = j < NABI ? ((const uint32_t*)msg)[e * NABI + j] : 0u;
         el = C::from_abi(w, k);
@@ -341,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
       }
     }
     const uint32_t o = C::to_abi(x, k);   // digest = state[0]
-    if (live && !odd && j < NABI) out[item * NABI + j] = o;
+    if (live && !odd && C::writer() && j < NABI) out[item * NABI + j] = o;
   }
 }
 

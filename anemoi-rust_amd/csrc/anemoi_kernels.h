@@ -29,6 +29,8 @@
 
 #include "anemoi_perm.h"
 #include "coop29.h"
+#include "coop2d.h"
+#include "options.h"
 
 namespace anemoi {
 
@@ -636,6 +638,7 @@ namespace anemoi {
 struct HostConsts {  // what the context uploads for one (field, width)
   std::vector<uint32_t> ark_c, ark_d;    // lane-private limb layout (F::Lane)
   std::vector<uint32_t> coop_c, coop_d;  // the instance's round constants in the cooperative kernels' layout (F::Coop)
+  std::vector<uint32_t> fold_c, fold_d;  // ... and in the two-row fold layout (F::Fold; width 2 only)
   std::vector<uint8_t> sched, sched5, sched_plain;
   int steps, first, steps5, first5, steps_plain, first_plain;
 };
@@ -692,9 +695,12 @@ struct Launch {
     hc->ark_c.assign(c, c + cnt);
     hc->ark_d.assign(d, d + cnt);
     using CL = typename F::Coop;
+    using FL = typename F::Fold;
     if (width == 2) {
       hc->coop_c.assign(CL::ArkC_21, CL::ArkC_21 + F::kRounds21 * CL::NL);
       hc->coop_d.assign(CL::ArkD_21, CL::ArkD_21 + F::kRounds21 * CL::NL);
+      hc->fold_c.assign(FL::ArkC_21, FL::ArkC_21 + F::kRounds21 * FL::NL);
+      hc->fold_d.assign(FL::ArkD_21, FL::ArkD_21 + F::kRounds21 * FL::NL);
     } else {
       hc->coop_c.assign(CL::ArkC_43, CL::ArkC_43 + 2 * F::kRounds43 * CL::NL);
       hc->coop_d.assign(CL::ArkD_43, CL::ArkD_43 + 2 * F::kRounds43 * CL::NL);
@@ -737,7 +743,12 @@ struct Launch {
   static hipError_t permutation(int width, int sbox_only, void* d, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
     // latency path: the cut-offs of the Jive kernels (same permutation, same items per wavefront)
-    if (!sbox_only && n <= (width == 2 ? coop4_max_items(F::Coop::NL) : coop43_max_items(F::Coop::NL))) {
+    if (!sbox_only && width == 2 && n <= coop2d_max_items(pc.simds)) {
+      const size_t groups = (n + 1) / 2;
+      k_permutation_coop<FIELD, 2, 32><<<unsigned(groups < 65536 ? groups : 65536), kBlock, 0, s>>>((uint32_t*)d, n, pc);
+      return hipGetLastError();
+    }
+    if (!sbox_only && n <= (width == 2 ? coop4_max_items(pc.simds) : coop43_max_items(pc.simds, F::Coop::NL))) {
       const size_t groups = width == 2 ? (n + 3) / 4 : (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       if (width == 2) k_permutation_coop<FIELD, 2><<<g, kBlock, 0, s>>>((uint32_t*)d, n, pc);
@@ -757,18 +768,24 @@ struct Launch {
 
   static hipError_t jive(int width, int k, const void* in, void* out, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (width == 2 && n <= coop_max_items(F::Coop::NL)) {  // latency path: one item per wavefront
+    if (width == 2 && n <= coop_max_items()) {  // latency path: one item per wavefront
       const unsigned g = n < 65536 ? unsigned(n) : 65536u;  // the kernel strides over items
       k_jive2_coop<FIELD, 64><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
-    if (width == 2 && n <= coop4_max_items(F::Coop::NL)) {  // four items per wavefront, one per DPP row
+    if (width == 2 && n <= coop2d_max_items(pc.simds)) {  // two items per wavefront on row pairs: the lowest latency
+      const size_t groups = (n + 1) / 2;
+      const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      k_jive2_coop<FIELD, 32><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
+      return hipGetLastError();
+    }
+    if (width == 2 && n <= coop4_max_items(pc.simds)) {  // four items per wavefront, one per DPP row
       const size_t groups = (n + 3) / 4;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       k_jive2_coop<FIELD, 16><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
-    if (width == 4 && n <= coop43_max_items(F::Coop::NL)) {  // 4-3 latency path: two states per wavefront
+    if (width == 4 && n <= coop43_max_items(pc.simds, F::Coop::NL)) {  // 4-3 latency path: two states per wavefront
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       if (k == 2) k_jive4_coop<FIELD, 2><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
@@ -787,7 +804,14 @@ struct Launch {
   static hipError_t sponge_seg(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
                                SpongeSeg seg, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (seg.first && seg.last && n <= coop_sponge_max_items(width, F::Coop::NL)) {  // latency path: whole small batches
+    if (seg.first && seg.last && width == 2 && n <= coop2d_max_items(pc.simds)) {  // lowest latency: two messages per wavefront
+      const size_t groups = (n + 1) / 2;
+      const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      if (bytes) k_sponge_coop<FIELD, 2, true, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
+      else k_sponge_coop<FIELD, 2, false, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
+      return hipGetLastError();
+    }
+    if (seg.first && seg.last && n <= coop_sponge_max_items(pc.simds)) {  // latency path: whole small batches
       const size_t groups = width == 2 ? (n + 3) / 4 : (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       if (width == 2 && bytes) k_sponge_coop<FIELD, 2, true><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
@@ -834,8 +858,15 @@ struct Launch {
   static hipError_t merkle_climb(const void* leaves, const void* index, const void* paths, unsigned depth, size_t n,
                                  void* out, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (n <= coop_sponge_max_items(2, F::Coop::NL)) {  // a handful of paths: the latency form (the sponge's cut-off:
-      const size_t groups = (n + 3) / 4;               // both keep a lane busy for many permutations in a row)
+    if (n <= coop2d_max_items(pc.simds)) {  // very few paths: two per wavefront on row pairs
+      const size_t groups = (n + 1) / 2;
+      const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      k_merkle_climb_coop<FIELD, 32><<<g, kBlock, 0, s>>>((const uint32_t*)leaves, (const uint64_t*)index,
+                                                           (const uint32_t*)paths, depth, n, (uint32_t*)out, pc);
+      return hipGetLastError();
+    }
+    if (n <= coop_climb_max_items(pc.simds)) {  // a handful of paths: the latency form
+      const size_t groups = (n + 3) / 4;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       k_merkle_climb_coop<FIELD><<<g, kBlock, 0, s>>>((const uint32_t*)leaves, (const uint64_t*)index,
                                                        (const uint32_t*)paths, depth, n, (uint32_t*)out, pc);

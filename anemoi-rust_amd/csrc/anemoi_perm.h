@@ -88,6 +88,12 @@ struct PermConsts {
   // the instance's round constants in the cooperative kernels' limb layout (F::Coop)
   const uint32_t* coop_c;
   const uint32_t* coop_d;
+  // ... and in the two-row fold layout (F::Fold, coop2d.h); Anemoi-2-1 only (null for width 4)
+  const uint32_t* fold_c;
+  const uint32_t* fold_d;
+  // host-side routing only: SIMDs of the device these tables live on (4 per CU); the automatic cut-offs of the
+  // latency kernels are multiples of it (anemoi_coop_kernels.h)
+  int simds;
 };
 
 // Source `SRC` of the extra digits' build programme (tools/gen_params.py): 0 = x, 1 = x^2, 2..4 = the LDS table

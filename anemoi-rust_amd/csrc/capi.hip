@@ -57,10 +57,7 @@ size_t elem_bytes(int field) { return size_t(anemoi::field_ops(field)->limbs64) 
 size_t quantum_of(int field, int kind, int width, int dev) {
   // per device: the occupancy query answers for the CURRENT device, and the CU count differs between
   // partition modes (SPX / CPX) and parts
-  if (const char* e = getenv("ANEMOI_TEST_QUANTUM")) {  // test knob: small quanta make small batches multi-chunk
-    const unsigned long long v = strtoull(e, nullptr, 10);
-    if (v) return size_t(v);
-  }
+  if (const long long v = anemoi::opt::get_or(anemoi::opt::kTestQuantum, 0)) return size_t(v);  // test knob: small quanta make small batches multi-chunk
   static std::mutex mu;
   static size_t cache[rt::kMaxDevices][anemoi::kNumFields][5][2] = {};
   const int wi = width == 2 ? 0 : 1;
@@ -338,15 +335,15 @@ int subtree_host(Lane& ln, TreeShape ts, const char* leaves, unsigned depth, cha
 // copied in; the sponge state travels from launch to launch in a device buffer (SpongeSeg).
 constexpr size_t kSegmentMinBytes = size_t(64) << 20;   // below this the single launch is kept
 
+// option "sponge_segment_bytes" (test knob): force the segment path, with (small) segments of this many bytes
+bool segments_forced() { return anemoi::opt::get(anemoi::opt::kSpongeSegmentBytes) != anemoi::opt::kAuto; }
 size_t segment_target_bytes() {
-  const char* e = getenv("ANEMOI_SPONGE_SEGMENT_BYTES");   // test knob: force (small) segments
-  if (e && *e) return size_t(strtoull(e, nullptr, 10));
-  return rt::kChunkTargetBytes;
+  return size_t(anemoi::opt::get_or(anemoi::opt::kSpongeSegmentBytes, (long long)rt::kChunkTargetBytes));
 }
 
 // unit = bytes of RATE elements of input (BYTES: RATE x chunk bytes; else RATE x element bytes)
 bool want_segments(size_t n, size_t per_msg_bytes, size_t unit) {
-  const bool forced = getenv("ANEMOI_SPONGE_SEGMENT_BYTES") != nullptr;
+  const bool forced = segments_forced();
   if (!forced && n * per_msg_bytes < kSegmentMinBytes) return false;
   size_t seg = segment_target_bytes() / (n ? n : 1) / unit * unit;
   if (seg < unit) seg = unit;
@@ -422,8 +419,11 @@ int sponge_host(int field, int width, int bytes, const void* src, size_t per_msg
       // MB of staging): feed blocks of at most one quantum of messages segment by segment.
       const size_t blk = count < 2 * quantum ? count : quantum;
       // (a batch small enough for the row-cooperative sponge is compute-bound by orders of magnitude -- one permutation
-      // per 1.4 ms against 93 bytes of input -- so it goes up in one piece and takes the latency kernel)
-      const bool latency_batch = count <= anemoi::coop_sponge_max_items(width, 0) && !getenv("ANEMOI_SPONGE_SEGMENT_BYTES");
+      // per 1.4 ms against 93 bytes of input -- so it goes up in one piece and takes the latency kernel; but only while
+      // "one piece" is small: a few LONG messages (4 096 x 16 MiB, one multi-GiB message) would otherwise need the
+      // whole batch on the device and in pinned staging at once, where the segment path holds three segments)
+      const bool latency_batch = count <= anemoi::coop_sponge_max_items(4 * rt::device_cus(dev)) &&
+                                 count * per_msg_bytes < kSegmentMinBytes && !segments_forced();
       if (!latency_batch && want_segments(blk, per_msg_bytes, unit) &&
           (count < 2 * quantum || quantum * per_msg_bytes > (size_t(256) << 20))) {
         for (size_t b = 0; b < count; b += blk) {
@@ -508,7 +508,7 @@ int merkle_host(TreeShape ts, const uint64_t* leaves, unsigned depth, uint64_t* 
 
 extern "C" {
 
-int anemoi_abi_version(void) { return 2; }
+int anemoi_abi_version(void) { return 3; }
 
 int anemoi_device_count(void) {
   int n = 0;
@@ -593,6 +593,22 @@ int anemoi_release(int device) {
   }
   for (int d = lo; d < hi; d++)
     if ((rc = rt::release_device(d))) return rc;
+  return ANEMOI_OK;
+}
+
+/* ---- options (options.h) ---- */
+
+int anemoi_set_option(const char* name, long long value) {
+  const int id = anemoi::opt::find(name);
+  if (id < 0 || !anemoi::opt::set(id, value)) return ANEMOI_ERR_ARG;
+  return ANEMOI_OK;
+}
+
+int anemoi_get_option(const char* name, long long* value) {
+  const int id = anemoi::opt::find(name);
+  if (id < 0 || !value) return ANEMOI_ERR_ARG;
+  *value = anemoi::opt::get(anemoi::opt::Id(id));
+  g_last_error = anemoi::opt::env_error();   // "" unless an environment value was rejected at start-up
   return ANEMOI_OK;
 }
 

@@ -34,8 +34,9 @@ struct Coop29 {
   using L = typename F::Coop;  // always the 29-bit layout: the systolic scan below sums a whole
                                // column (2 NL products) in one 64-bit lane accumulator
   static_assert(L::W == 29, "column sums of 2 NL limb products must fit 64 bits");
-  static constexpr int NL = L::NL;
+  static constexpr int NL = L::NL, W = 29;
   static constexpr int NABI = F::N;
+  static constexpr int kLanesPerItem = LPR;
   static constexpr uint32_t MASK = (1u << 29) - 1;
   static constexpr bool kTight = L::kTight;
 
@@ -50,6 +51,7 @@ struct Coop29 {
   __device__ static __forceinline__ uint32_t limb() { return threadIdx.x & (LPR - 1); }       // j: which limb this lane holds
   __device__ static __forceinline__ uint32_t row0() { return threadIdx.x & ~uint32_t(LPR - 1); }  // first lane of the element
   __device__ static __forceinline__ uint32_t keep(uint32_t v) { return limb() < NL ? v : 0u; }
+  __device__ static __forceinline__ bool writer() { return true; }   // every lane of an element stores its own word
 
   // per-lane copy of a field constant (limb j, 0 beyond NL)
   __device__ static __forceinline__ uint32_t konst(const uint32_t* __restrict__ k) {
@@ -131,6 +133,11 @@ struct Coop29 {
       static_for_limbs<I + 1>(fn);
     }
   }
+
+  // the forms the kernels call (the same on Coop2d, whose product needs more than the modulus)
+  __device__ static __forceinline__ uint32_t mul(uint32_t a, uint32_t b, const K& k) { return mul(a, b, k.pl); }
+  __device__ static __forceinline__ uint32_t sub(uint32_t a, uint32_t b, const K& k) { return sub(a, b, k.kpl); }
+  __device__ static __forceinline__ uint32_t to_mont(uint32_t x, const K& k) { return mul(x, k.rr, k.pl); }
 
   __device__ static __forceinline__ uint32_t add(uint32_t a, uint32_t b) { return carry32(a + b); }
 

@@ -1,0 +1,267 @@
+// coop2d.h -- the TWO-ROW ("2-D") cooperative Montgomery arithmetic: one field element on a PAIR of 16-lane DPP rows,
+// two elements per wavefront.  The lowest-latency path (batches of at most two items per SIMD: the top levels of a
+// Merkle tree, a single Jive::compress / Sponge::merge / hash through the shim).
+//
+// coop29.h's product is a digit-serial scan: NL steps of ten issue slots, each waiting for the quotient digit of the
+// step before.  A lone wavefront issues one instruction per ~4.7 cycles whatever the dependences, so the latency of a
+// compression is the INSTRUCTION COUNT of its ~6 500 / ~10 000 sequential products.  This layout spreads a product
+// over two rows and removes the quotient digits altogether (tools/coop2d_model.py is the executable specification):
+//
+//   layout   NL limbs of W = 28 bits, limb j in lane j of BOTH rows of the pair (lanes >= NL hold zero), Montgomery
+//            form with R' = 2^(28 NL), NL chosen so that R'/p >= 2^34 (11 limbs for the 255-bit fields, 15 for the
+//            381/377-bit ones): values are only kept below 2^35 p, never below 2p
+//   P1       T = a x b, schoolbook, row h multiplying by the limbs a_i with i = h (mod 2): Q = ceil(NL/2) steps of
+//            [row broadcast of a_i, two lane shifts of b, two v_mad_u64_u32].  Lane l of LO sums column l - OFF
+//            (OFF = 16 - NL), lane l of HI column NL + l: the high half lands where result limb l will live
+//   RN1      the low columns are summed over the two rows (v_permlane16_swap) and carried to limbs t_k < 2^28 + 2^5;
+//            the carry out of column NL - 1 goes to HI lane 0
+//   P2       the low half is folded away by a TABLE instead of the two further products of a Montgomery reduction:
+//                T R'^-1  =  TH + sum_k t_k C_k   (mod p),     C_k = 2^(28 k) R'^-1 mod p,
+//            C_k[l] per-lane constants (Q registers), the k split over the rows by parity again, accumulated ONTO HI
+//   RN2      HI is carried per row, summed over the rows, carried again: limbs < 2^28 + 2^5, value < 2^33 p
+//
+// ~75 (11 limbs) / ~95 (15 limbs) issue slots per product against ~108 / ~158 for the scan.  The price: results are
+// never tight, so (i) every difference is settled at once (sub() multiplies by R' mod p), (ii) the one product whose
+// result has to be < 2p -- the conversion to the ABI form -- runs a digit-serial scan in the same layout (mul_exact),
+// once per output element.
+//
+// Same interface as Coop29 (coop29.h), so the latency kernels of anemoi_coop_kernels.h are instantiated on either.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <type_traits>
+
+#include "field_consts_gen.h"
+
+namespace anemoi {
+
+template <class F>
+struct Coop2d {
+  using L = typename F::Fold;
+  static constexpr int W = L::W, NL = L::NL, Q = L::Q, OFF = L::OFF;
+  static constexpr int NABI = F::N;
+  static constexpr int kLanesPerItem = 32;   // two 16-lane rows
+  static constexpr uint32_t MASK = (1u << W) - 1;
+  static_assert(W == 28 && NL <= 15 && OFF == 16 - NL && Q == (NL + 1) / 2, "layout of tools/coop2d_model.py");
+
+  // ---- DPP / cross-row primitives ---------------------------------------------------------------------------------
+  template <int CTRL>
+  __device__ static __forceinline__ uint32_t dppz(uint32_t v) {  // all rows, out-of-range sources read as 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+  }
+  template <int N>
+  __device__ static __forceinline__ uint32_t shr(uint32_t v) {  // lane l <- lane l - N
+    if constexpr (N == 0) return v;
+    else if constexpr (N > 15) return 0u;
+    else return dppz<0x110 + N>(v);
+  }
+  template <int N>
+  __device__ static __forceinline__ uint32_t shl(uint32_t v) {  // lane l <- lane l + N
+    if constexpr (N == 0) return v;
+    else if constexpr (N > 15) return 0u;
+    else return dppz<0x100 + N>(v);
+  }
+  template <int N>
+  __device__ static __forceinline__ uint32_t bcast(uint32_t v) {  // lane N of each row to the whole row
+    // (bound_ctrl set: every source lane of a row broadcast exists, and without it hipcc materialises the `old`
+    // operand with a v_mov and a hazard s_nop in front of every broadcast)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xf, 0xf, true);
+  }
+  __device__ static __forceinline__ uint32_t from_prev(uint32_t v) { return shr<1>(v); }
+  // only the odd row of each pair is rewritten (row_mask 0xa); the even row keeps v
+  __device__ static __forceinline__ uint32_t odd_rows_from_next(uint32_t v) {  // "D form": odd row lane l holds limb l+1
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x101, 0xa, 0xf, true);
+  }
+  __device__ static __forceinline__ uint32_t odd_rows_from_prev(uint32_t v) {  // "S form": odd row lane l holds limb l-1
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xa, 0xf, true);
+  }
+  // v_permlane16_swap: the odd rows of `a` change places with the even rows of `b`
+  __device__ static __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+  }
+  // sum over the two rows of a pair, in both rows
+  __device__ static __forceinline__ uint32_t pair_sum(uint32_t v) {
+    uint32_t x = v;
+    swap16(v, x);  // v = [even, even], x = [odd, odd]
+    return v + x;
+  }
+
+  __device__ static __forceinline__ uint32_t lane() { return threadIdx.x; }
+  __device__ static __forceinline__ uint32_t limb() { return threadIdx.x & 15u; }
+  __device__ static __forceinline__ uint32_t row0() { return threadIdx.x & ~15u; }   // first lane of this lane's row
+  __device__ static __forceinline__ bool odd_row() { return (threadIdx.x >> 4) & 1u; }
+  __device__ static __forceinline__ bool writer() { return !odd_row(); }             // the row that stores results
+  __device__ static __forceinline__ uint32_t keep(uint32_t v) { return limb() < NL ? v : 0u; }
+  __device__ static __forceinline__ uint32_t konst(const uint32_t* __restrict__ k) {
+    return limb() < NL ? k[limb()] : 0u;
+  }
+
+  struct K {
+    uint32_t pl, kpl, delta, one, gm, in, out, rr;
+    uint32_t ct[Q];   // fold table: row h, lane l, step q holds limb l of C_(2q+h)
+  };
+  __device__ static __forceinline__ K load_consts() {
+    K k{konst(L::P), konst(L::KP), konst(L::Delta), konst(L::One), konst(L::GMont), konst(L::In), konst(L::Out),
+        konst(L::RR), {}};
+    const uint32_t h = odd_row() ? 1u : 0u;
+#pragma unroll
+    for (int q = 0; q < Q; q++) k.ct[q] = L::FoldT[(q * 2 + h) * 16 + limb()];
+    return k;
+  }
+
+  // one carry pass for sums of a few almost-normalised limbs (values < 2^32)
+  __device__ static __forceinline__ uint32_t carry32(uint32_t r) { return keep((r & MASK) + from_prev(r >> W)); }
+
+  // limbs < 2^29 -> limbs < 2^28 exactly: carry look-ahead on two wavefront ballots (coop29.h); lanes >= NL of every
+  // row are zero, neither generate nor propagate, so no carry crosses a row
+  __device__ static __forceinline__ uint32_t norm_exact(uint32_t r) {
+    r = carry32(r);
+    const unsigned long long G = __ballot(r > MASK), P = __ballot(r == MASK);
+    const unsigned long long C = ((G << 1) + P) ^ P;
+    return (r + (uint32_t)((C >> lane()) & 1)) & MASK;
+  }
+
+  // per row: 64-bit column sums -> limbs < 2^W + 2^5 (two carry passes); `hi` and `wh` are handed back for the caller
+  // that needs what the top lane shifts out
+  __device__ static __forceinline__ uint32_t row_carry(uint64_t acc, uint32_t& hi, uint32_t& wh) {
+    const uint32_t lo = (uint32_t)acc & MASK;
+    hi = (uint32_t)(acc >> W);
+    const uint32_t w = lo + from_prev(hi);
+    wh = w >> W;
+    return (w & MASK) + from_prev(wh);
+  }
+
+  template <int I, class Fn>
+  __device__ static __forceinline__ void static_for(Fn&& fn) {   // fn(integral_constant<q>) for q = I .. Q-1
+    if constexpr (I < Q) {
+      fn(std::integral_constant<int, I>{});
+      static_for<I + 1>(fn);
+    }
+  }
+
+  // a * b * R'^-1 mod p, lazily: result < (A B / H + NL 2^W) p for a < A p, b < B p; limbs < 2^W + 2^5.
+  // tools/coop2d_model.py::mul is this function lane for lane.
+  __device__ static __forceinline__ uint32_t mul(uint32_t a, uint32_t b, const K& k) {
+    const uint32_t aD = odd_rows_from_next(a), bS = odd_rows_from_prev(b);
+    uint64_t LO = 0, HI = 0;
+    static_for<0>([&](auto I) {   // P1
+      constexpr int q = decltype(I)::value;
+      const uint32_t aq = bcast<2 * q>(aD);
+      LO += (uint64_t)aq * shr<OFF + 2 * q>(bS);
+      HI += (uint64_t)aq * shl<NL - 2 * q>(bS);
+    });
+    // RN1: low columns (LO lanes OFF..15) -> limbs t; what leaves the top lane is the carry into column NL = HI lane 0
+    uint32_t t;
+    if constexpr (NL <= 13) {   // sum over the rows first: sum of the high parts <= NL 2^W, v < (NL + 2) 2^W
+      uint32_t lo = (uint32_t)LO & MASK, hi = (uint32_t)(LO >> W);
+      swap16(lo, hi);
+      uint32_t s = lo + hi;     // even row: sum of the low parts; odd row: sum of the high parts
+      uint32_t x = s;
+      swap16(s, x);             // s = low parts, x = high parts, in both rows
+      const uint32_t v = s + from_prev(x), vh = v >> W;
+      const uint32_t cc = x + vh;   // lane 15: everything column NL-1 hands on; lanes 0..2 are zero (OFF >= 3)
+      static_assert(NL > 13 || OFF >= 3, "the carry injection relies on empty lanes 0..2");
+      t = (v & MASK) + from_prev(vh);
+      // rows 0 and 2 only (the rows are summed in RN2), lane 0 <- lane 15 (row_ror:1, bank 0 = lanes 0..3)
+      HI += (uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)cc, 0x121, 0x5, 0x1, false);
+    } else {                    // 15 limbs: carry inside each row first, then sum over the rows
+      uint32_t hi, wh;
+      const uint32_t w2 = row_carry(LO, hi, wh);
+      const uint32_t ccr = limb() == 15 ? hi + wh : 0u;   // this row's share of the carry into column NL
+      HI += (uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)ccr, 0x121, 0xf, 0x1, false);
+      const uint32_t y = pair_sum(w2), yh = y >> W;
+      t = (limb() == 15 ? y : (y & MASK)) + from_prev(yh);   // the top limb keeps its own carry (t_15 < 2^29 + 2^6)
+    }
+    // P2: fold the low half with the table
+    const uint32_t tD = odd_rows_from_next(t);
+    static_for<0>([&](auto I) {
+      constexpr int q = decltype(I)::value;
+      HI += (uint64_t)bcast<OFF + 2 * q>(tD) * k.ct[q];
+    });
+    // RN2
+    uint32_t hi, wh;
+    const uint32_t w2 = row_carry(HI, hi, wh);
+    const uint32_t y = pair_sum(w2);
+    // (lanes >= NL stay zero by themselves: no product or table entry reaches them and the value is far below R')
+    return (y & MASK) + from_prev(y >> W);
+  }
+
+  // Digit-serial Montgomery product (the scan of coop29.h on this layout, both rows doing the same work): result
+  // < (A B / H + 1) p.  Only where a result has to be < 2p: the conversion to the ABI form.
+  template <int I, class Fn>
+  __device__ static __forceinline__ void static_for_limbs(Fn&& fn) {
+    if constexpr (I < NL) {
+      fn(std::integral_constant<int, I>{});
+      static_for_limbs<I + 1>(fn);
+    }
+  }
+  __device__ static __forceinline__ uint32_t mul_exact(uint32_t a, uint32_t b, uint32_t pl) {
+    const uint32_t sh = limb() == 0 ? uint32_t(W) : 63u;
+    uint64_t t = 0;
+    static_for_limbs<0>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      t += (uint64_t)bcast<i>(a) * b;
+      const uint32_t m = (bcast<0>((uint32_t)t) * L::kN0Inv) & MASK;
+      t += (uint64_t)m * pl;
+      const uint64_t u = t >> sh;   // lane 0: the retired column's carry; elsewhere 0 (column sums < 2^63)
+      t = (((uint64_t)shl<1>((uint32_t)(t >> 32)) << 32) | shl<1>((uint32_t)t)) + u;
+    });
+    const uint32_t lo = (uint32_t)t & MASK;
+    const uint64_t hi = t >> W;
+    const uint64_t up = ((uint64_t)from_prev((uint32_t)(hi >> 32)) << 32) | from_prev((uint32_t)hi);
+    const uint64_t r = (uint64_t)lo + up;
+    return keep(((uint32_t)r & MASK) + from_prev((uint32_t)(r >> W)));
+  }
+
+  __device__ static __forceinline__ uint32_t add(uint32_t a, uint32_t b) { return carry32(a + b); }
+  __device__ static __forceinline__ uint32_t settle(uint32_t x, const K& k) { return mul(x, k.one, k); }
+
+  // a - b + 2^s p, settled at once: b < 2^s p (what the S-box subtracts: g * product or a product, field_consts_gen.h)
+  __device__ static __forceinline__ uint32_t sub(uint32_t a, uint32_t b, const K& k) {
+    return settle(carry32(a + k.kpl - norm_exact(b)), k);
+  }
+
+  // g * x (mul_by_generator, src/traits.rs:78-91)
+  __device__ static __forceinline__ uint32_t mul_g(uint32_t x, const K& k) {
+    if constexpr (L::kScaleG) return carry32(x * (uint32_t)F::kG);
+    else return mul(x, k.gm, k);
+  }
+
+  // x < 2p -> x mod p, exact limbs (borrow look-ahead, as coop29.h)
+  __device__ static __forceinline__ uint32_t canonical(uint32_t x, uint32_t pl) {
+    x = norm_exact(x);
+    const unsigned long long G = __ballot(x < pl), P = __ballot(x == pl && limb() < NL);
+    const unsigned long long B = ((G << 1) + P) ^ P;
+    const bool below = (((G << 1) + P) >> (row0() + NL)) & 1;
+    const uint32_t d = (x - pl - (uint32_t)((B >> lane()) & 1)) & MASK;
+    return below ? x : keep(d);
+  }
+
+  // ABI words (lane j < NABI holds 32-bit word j) <-> limbs
+  __device__ static __forceinline__ uint32_t words_to_limbs(uint32_t w) {
+    const int bit = W * (int)limb(), lo = bit >> 5, sh = bit & 31, r0 = (int)row0();
+    const uint32_t wl = __shfl(w, r0 + (lo < NABI ? lo : 0)), wh = __shfl(w, r0 + (lo + 1 < NABI ? lo + 1 : 0));
+    const uint32_t a = lo < NABI ? wl : 0u, b = lo + 1 < NABI ? wh : 0u;
+    const uint32_t v = sh == 0 ? a : ((a >> sh) | (b << (32 - sh)));
+    return keep(v & MASK);
+  }
+  __device__ static __forceinline__ uint32_t limbs_to_words(uint32_t l) {  // exact limbs, value < 2^(32 NABI)
+    const int bit = 32 * (int)limb(), i0 = bit / W, off = bit - W * i0, r0 = (int)row0();
+    const uint32_t l0 = __shfl(l, r0 + (i0 < 16 ? i0 : 0)), l1 = __shfl(l, r0 + (i0 + 1 < 16 ? i0 + 1 : 0)),
+                   l2 = __shfl(l, r0 + (i0 + 2 < 16 ? i0 + 2 : 0));
+    uint32_t v = i0 < 16 ? l0 >> off : 0u;
+    if (i0 + 1 < 16) v |= l1 << (W - off);
+    if (2 * W - off < 32 && i0 + 2 < 16) v |= l2 << (2 * W - off);
+    return limb() < NABI ? v : 0u;
+  }
+  __device__ static __forceinline__ uint32_t from_abi(uint32_t w, const K& k) { return mul(words_to_limbs(w), k.in, k); }
+  __device__ static __forceinline__ uint32_t to_abi(uint32_t x, const K& k) {
+    return limbs_to_words(canonical(mul_exact(x, k.out, k.pl), k.pl));
+  }
+  // plain integer < 2^(W NL) (limbs) -> Montgomery form
+  __device__ static __forceinline__ uint32_t to_mont(uint32_t x, const K& k) { return mul(x, k.rr, k); }
+};
+
+}  // namespace anemoi

@@ -186,10 +186,10 @@ inline int get_consts(int field, int width, PermConsts* out) {
       return w;
     };
     const std::vector<uint32_t> s3 = words(hc.sched), s5 = words(hc.sched5), sp = words(hc.sched_plain);
-    const std::vector<uint32_t>* parts[7] = {&hc.ark_c, &hc.ark_d, &s3, &s5, &hc.coop_c, &hc.coop_d, &sp};
-    size_t off[8] = {0};
+    const std::vector<uint32_t>* parts[9] = {&hc.ark_c, &hc.ark_d, &s3, &s5, &hc.coop_c, &hc.coop_d, &sp, &hc.fold_c, &hc.fold_d};
+    size_t off[10] = {0};
     std::vector<uint32_t> host;
-    for (int i = 0; i < 7; i++) {
+    for (int i = 0; i < 9; i++) {
       off[i + 1] = off[i] + parts[i]->size();
       host.insert(host.end(), parts[i]->begin(), parts[i]->end());
     }
@@ -212,8 +212,16 @@ inline int get_consts(int field, int width, PermConsts* out) {
     pc.coop_c = blob + off[4];
     pc.coop_d = blob + off[5];
     pc.sched_plain = blob + off[6];
+    pc.fold_c = hc.fold_c.empty() ? nullptr : blob + off[7];
+    pc.fold_d = hc.fold_d.empty() ? nullptr : blob + off[8];
     pc.steps_plain = hc.steps_plain;
     pc.first_plain = hc.first_plain;
+    if (!c.num_cus) {  // (device_cus() takes this same mutex)
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      c.num_cus = n;
+    }
+    pc.simds = 4 * c.num_cus;
     c.pc[field][wi] = pc;
     c.blob[field][wi] = blob;
     c.ready[field][wi] = true;
@@ -324,15 +332,11 @@ inline int physical_devices(int* ndev) {
   return ANEMOI_OK;
 }
 
-// Number of ranges ANEMOI_ALL_DEVICES cuts a batch into: the GPU count, or ANEMOI_VIRTUAL_DEVICES (test
-// knob, read at every call so a test can switch it inside one process).
+// Number of ranges ANEMOI_ALL_DEVICES cuts a batch into: the GPU count, or the option "virtual_devices" (test
+// knob: anemoi_set_option, or ANEMOI_VIRTUAL_DEVICES read once; options.h).
 inline int shard_parts(int ndev) {
-  const char* e = getenv("ANEMOI_VIRTUAL_DEVICES");
-  if (e && *e) {
-    const long v = strtol(e, nullptr, 10);
-    if (v >= 1 && v <= kMaxDevices) return int(v);
-  }
-  return ndev;
+  const long long v = opt::get(opt::kVirtualDevices);
+  return v >= 1 && v <= kMaxDevices ? int(v) : ndev;
 }
 
 // Runs `body(part, device, first, count)` for every part: one host thread per DEVICE, which works through its
@@ -380,25 +384,13 @@ int for_devices(int device, size_t n, Body body) {
   return run_parts(parts, ndev, n, [&](int, int dev, size_t first, size_t count) { return body(dev, first, count); });
 }
 
-// Input bytes per chunk of the host-pointer pipelines.  ANEMOI_CHUNK_TARGET_BYTES is a test knob (read at every
-// call): small values make small batches run through many chunks, so the slot ring wraps in the tests.
-inline size_t chunk_target_bytes() {
-  const char* e = getenv("ANEMOI_CHUNK_TARGET_BYTES");
-  if (e && *e) {
-    const unsigned long long v = strtoull(e, nullptr, 10);
-    if (v) return size_t(v);
-  }
-  return kChunkTargetBytes;
-}
+// Input bytes per chunk of the host-pointer pipelines.  The option "chunk_target_bytes" is a test knob: small
+// values make small batches run through many chunks, so the slot ring wraps in the tests.
+inline size_t chunk_target_bytes() { return size_t(opt::get_or(opt::kChunkTargetBytes, (long long)kChunkTargetBytes)); }
 
 // 0 = copy straight from / to the caller's memory (HIP stages pageable memory itself);
 // 1 = stage through the lane's pinned buffers (host memcpy + truly asynchronous DMA).
-inline int staging_mode() {
-  const char* e = getenv("ANEMOI_HOST_STAGING");
-  if (e && !strcmp(e, "direct")) return 0;
-  if (e && !strcmp(e, "pinned")) return 1;
-  return 1;
-}
+inline int staging_mode() { return int(opt::get_or(opt::kHostStaging, 1)); }
 
 // Is [p, p + bytes) host memory that HIP already knows as pinned (hipHostMalloc / hipHostRegister)?  Then the
 // DMA engines can read / write it directly and staging would only add a memcpy.

@@ -37,11 +37,9 @@
  * copy (not legal inside a stream capture): call anemoi_init() beforehand to get that out of the way.
  * Input and output ranges of a `_dev` Jive call must not overlap (ANEMOI_ERR_ARG).
  *
- * ENVIRONMENT (diagnostics): ANEMOI_VIRTUAL_DEVICES=N makes ANEMOI_ALL_DEVICES shard into N ranges /
- * subtrees mapped round-robin onto the physical GPUs (exercises the multi-GPU code on one GPU);
- * ANEMOI_HOST_STAGING=direct|pinned selects how host buffers are copied; ANEMOI_SPONGE_SEGMENT_BYTES forces the
- * segment size of the sponge's host path (long messages are absorbed segment by segment, copies under kernels);
- * ANEMOI_COOP_MAX overrides the batch size below which Jive 2-to-1 takes the wave-cooperative latency kernel.
+ * OPTIONS: the kernel-selection cut-offs and the test / diagnostic knobs are listed with anemoi_set_option below.
+ * Each is read from its environment variable ONCE (first use) and changed afterwards only through the API; no entry
+ * point calls getenv() when it launches.
  */
 #ifndef ANEMOI_MI355X_H
 #define ANEMOI_MI355X_H
@@ -96,6 +94,37 @@ int anemoi_num_rounds(int field, int width); /* NUM_HASH_ROUNDS, src/<f>/anemoi_
  * kernels read the constant tables.  The library can be used again afterwards (it re-initialises lazily). */
 int anemoi_init(int device, int field, int width);
 int anemoi_release(int device);
+
+/* ---- options --------------------------------------------------------------------------------
+ * anemoi_set_option(name, value): value -1 = automatic (the default).  `name` is the option name or its environment
+ * variable.  Each option starts from its environment variable, read and validated ONCE at first use (a value that is
+ * not a whole number in range is ignored; anemoi_last_error() after anemoi_get_option says so).  Unknown name or
+ * value out of range: ANEMOI_ERR_ARG.  Changing an option affects calls that START afterwards.
+ *
+ *   name                   environment                  automatic value                meaning
+ *   coop2d_max             ANEMOI_COOP2D_MAX            2 x SIMDs of the device        largest 2-1 batch (Jive / merge, permutation, sponge, path
+ *                                                                                      climb) on the two-row 2-D latency kernels (two items per
+ *                                                                                      wavefront, lowest latency); 0 = never
+ *   coop4_max              ANEMOI_COOP4_MAX             8 x SIMDs                      largest Jive 2-1 / permutation batch on the row-cooperative
+ *                                                                                      kernel (four items per wavefront); above: lane-private
+ *   coop43_max             ANEMOI_COOP43_MAX            2 x SIMDs (4-limb fields),     the same for Anemoi-4-3 (two states per wavefront)
+ *                                                       4 x SIMDs (6-limb)
+ *   coop_sponge_max        ANEMOI_COOP_SPONGE_MAX       4 x SIMDs                      largest equal-length sponge batch on the cooperative kernel
+ *   coop_climb_max         ANEMOI_COOP_CLIMB_MAX        4 x SIMDs                      largest batch of authentication paths on the cooperative kernel
+ *   coop_max               ANEMOI_COOP_MAX              0                              one-item-per-wavefront scan kernel (A/B and parity only)
+ *   merkle_subtrees_log2   ANEMOI_MERKLE_SUBTREES_LOG2  by depth                       a device-resident Merkle build climbs 2^v subtrees on
+ *                                                                                      separate streams (narrow levels of one under the wide levels of
+ *                                                                                      another); 0 = level by level on one stream
+ *   virtual_devices        ANEMOI_VIRTUAL_DEVICES       the GPU count                  ANEMOI_ALL_DEVICES shards into this many ranges / subtrees,
+ *                                                                                      mapped round-robin onto the GPUs (multi-GPU code on one GPU)
+ *   host_staging           ANEMOI_HOST_STAGING          1 ("pinned")                   1: host buffers go through the lane's pinned staging;
+ *                                                                                      0 ("direct"): copied straight from / to the caller's memory
+ *   chunk_target_bytes     ANEMOI_CHUNK_TARGET_BYTES    24 MiB                         input bytes per chunk of the host pipelines (test knob)
+ *   test_quantum           ANEMOI_TEST_QUANTUM          occupancy API                  items per full wave of workgroups (test knob)
+ *   sponge_segment_bytes   ANEMOI_SPONGE_SEGMENT_BYTES  by batch shape                 forces the segment-fed sponge, this many bytes per segment
+ */
+int anemoi_set_option(const char *name, long long value);
+int anemoi_get_option(const char *name, long long *value); /* the value in force; -1 = automatic */
 
 /* ---- host-pointer batch API -------------------------------------------------------------- */
 

@@ -17,6 +17,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+class knobs:
+    """Library options for the duration of a with-block, through anemoi_set_option (options are read from the
+    environment once and changed only through the API; names are option names or their ANEMOI_* variables).
+    None = the automatic default."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        import anemoi_amd as A
+        self.prev = {k: A.get_option(k) for k in self.kv}
+        for k, v in self.kv.items():
+            A.set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        import anemoi_amd as A
+        for k, v in self.prev.items():
+            A.set_option(k, v)
+        return False
+
+
 def inst_key(field, width):
     return "%s/anemoi_%s" % (field, "2_1" if width == 2 else "4_3")
 

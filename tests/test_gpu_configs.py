@@ -17,7 +17,7 @@ import time
 import numpy as np
 import pytest
 
-from conftest import FIELD_IDS, ROOT
+from conftest import FIELD_IDS, ROOT, knobs
 
 pytestmark = pytest.mark.gpu
 
@@ -41,24 +41,9 @@ def golden():
         return json.load(f)
 
 
-class virtual_devices:
-    """ANEMOI_VIRTUAL_DEVICES=n for the duration of a with-block (the library reads it at every call)."""
-
-    def __init__(self, n):
-        self.n = n
-
-    def __enter__(self):
-        self.prev = os.environ.get("ANEMOI_VIRTUAL_DEVICES")
-        if self.n is None:
-            os.environ.pop("ANEMOI_VIRTUAL_DEVICES", None)
-        else:
-            os.environ["ANEMOI_VIRTUAL_DEVICES"] = str(self.n)
-
-    def __exit__(self, *exc):
-        if self.prev is None:
-            os.environ.pop("ANEMOI_VIRTUAL_DEVICES", None)
-        else:
-            os.environ["ANEMOI_VIRTUAL_DEVICES"] = self.prev
+def virtual_devices(n):
+    """option virtual_devices = n for the duration of a with-block"""
+    return knobs(virtual_devices=n)
 
 
 def sha(a):
@@ -244,9 +229,7 @@ def test_real_multi_gpu_all_devices(A, oracle):
 def test_chunked_pipeline_both_staging_modes(A, oracle, staging):
     """Batches well beyond one chunk (so the 3-slot ring wraps) through both copy strategies, in place and
     out of place; a strided sample against the oracle and all items against the small-batch path."""
-    prev = os.environ.get("ANEMOI_HOST_STAGING")
-    os.environ["ANEMOI_HOST_STAGING"] = staging
-    try:
+    with knobs(host_staging=staging):
         fid = FIELD_IDS.index("jubjub")
         inst = A.Anemoi("jubjub", 2)
         rng = np.random.default_rng(11)
@@ -261,11 +244,6 @@ def test_chunked_pipeline_both_staging_modes(A, oracle, staging):
         p1 = A.Anemoi("bn_254", 4).permutation_batch(base4[idx4])  # in place on the device
         p0 = A.Anemoi("bn_254", 4).permutation_batch(base4)
         assert (p1 == p0[idx4]).all()
-    finally:
-        if prev is None:
-            os.environ.pop("ANEMOI_HOST_STAGING", None)
-        else:
-            os.environ["ANEMOI_HOST_STAGING"] = prev
 
 
 def test_sponge_fed_segment_by_segment(A, oracle, synth):
@@ -273,26 +251,20 @@ def test_sponge_fed_segment_by_segment(A, oracle, synth):
     device buffer): force tiny segments and compare byte and element messages of lengths around the segment
     and rate boundaries with the oracle, Anemoi-2-1 (rate 1) and 4-3 (rate 3), 4- and 6-limb fields."""
     rng = np.random.default_rng(21)
-    prev = os.environ.get("ANEMOI_SPONGE_SEGMENT_BYTES")
-    try:
+    with knobs(sponge_segment_bytes=None):
         for field, width, n in (("bn_254", 4, 70), ("jubjub", 2, 33), ("bls12_381", 4, 40), ("bls12_377", 2, 5)):
             fid, inst = FIELD_IDS.index(field), A.Anemoi(field, width)
             unit = (width - 1) * inst.chunk
-            os.environ["ANEMOI_SPONGE_SEGMENT_BYTES"] = str(n * unit * 2)          # 2 rate-blocks per segment
+            A.set_option("sponge_segment_bytes", n * unit * 2)          # 2 rate-blocks per segment
             seg = 2 * unit
             for ln in (2 * seg + 1, 3 * seg, 3 * seg - 1, 3 * seg + inst.chunk, 5 * seg + 7, 10 * seg):
                 msgs = rng.integers(0, 256, size=(n, ln), dtype=np.uint8)
                 assert (inst.hash_batch(msgs) == oracle.hash_bytes_batch(fid, width, msgs, threads=8)).all(), (field, width, ln)
             eunit = (width - 1) * inst.limbs * 8
-            os.environ["ANEMOI_SPONGE_SEGMENT_BYTES"] = str(n * eunit * 2)
+            A.set_option("sponge_segment_bytes", n * eunit * 2)
             for ne in (4 * (width - 1) + 1, 6 * (width - 1), 6 * (width - 1) + 2, 13 * (width - 1)):
                 el = synth.elements(field, 99, 0, n * ne).reshape(n, ne, inst.limbs)     # every element < p
                 assert (inst.hash_field_batch(el) == oracle.hash_field_batch(fid, width, el, threads=8)).all(), (field, width, ne)
-    finally:
-        if prev is None:
-            os.environ.pop("ANEMOI_SPONGE_SEGMENT_BYTES", None)
-        else:
-            os.environ["ANEMOI_SPONGE_SEGMENT_BYTES"] = prev
 
 
 def test_many_long_messages_go_block_by_block_through_the_segment_path(A, oracle, synth):

@@ -12,7 +12,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import FIELD_IDS
+from conftest import FIELD_IDS, knobs
 
 pytestmark = pytest.mark.gpu
 
@@ -30,28 +30,6 @@ def R():
     return anemoi_ref
 
 
-class env:
-    """environment knobs for the duration of a with-block (the library reads them at every call)"""
-
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.prev = {k: os.environ.get(k) for k in self.kv}
-        for k, v in self.kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = str(v)
-
-    def __exit__(self, *exc):
-        for k, v in self.prev.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
 @pytest.mark.parametrize("staging", ["pinned", "direct"])
 def test_ragged_sponge_through_many_chunks(A, oracle, staging):
     """~700 messages of 0..300 bytes plus a few far longer than the chunk target, cut into chunks of <= 4 KB of
@@ -64,15 +42,15 @@ def test_ragged_sponge_through_many_chunks(A, oracle, staging):
             lens[pos] = ln
         msgs = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for n in lens]
         whole = inst.hash_ragged(msgs)                      # one chunk (default target)
-        with env(ANEMOI_CHUNK_TARGET_BYTES=4096, ANEMOI_TEST_QUANTUM=128, ANEMOI_HOST_STAGING=staging):
+        with knobs(chunk_target_bytes=4096, test_quantum=128, host_staging=staging):
             got = inst.hash_ragged(msgs)
-            with env(ANEMOI_VIRTUAL_DEVICES=3):
+            with knobs(virtual_devices=3):
                 many = A.Anemoi(field, width, device=A.ALL_DEVICES).hash_ragged(msgs)
         assert (got == whole).all() and (many == whole).all(), (field, width)
         for i in list(range(0, 700, 7)) + [5, 64, 65, 333, 699]:
             assert (got[i] == oracle.hash_bytes(fid, width, msgs[i])).all(), (field, width, i, lens[i])
         # all-empty batch and a batch of one long message
-        with env(ANEMOI_CHUNK_TARGET_BYTES=4096, ANEMOI_TEST_QUANTUM=128, ANEMOI_HOST_STAGING=staging):
+        with knobs(chunk_target_bytes=4096, test_quantum=128, host_staging=staging):
             assert (inst.hash_ragged([b""] * 200) == 0).all()
             one = inst.hash_ragged([msgs[333]])
         assert (one[0] == whole[333]).all()
@@ -114,9 +92,9 @@ def test_path_verification_through_many_chunks(A, oracle, R, staging):
             else:
                 idx[i] ^= 1                                                # right leaf, wrong slot
         whole = verify(sel, idx, paths, depth, root)
-        with env(ANEMOI_CHUNK_TARGET_BYTES=1, ANEMOI_TEST_QUANTUM=128, ANEMOI_HOST_STAGING=staging):
+        with knobs(chunk_target_bytes=1, test_quantum=128, host_staging=staging):
             got = verify(sel, idx, paths, depth, root)
-            with env(ANEMOI_VIRTUAL_DEVICES=3):
+            with knobs(virtual_devices=3):
                 sharded = A.Anemoi(field, width, device=A.ALL_DEVICES)
                 many = (sharded.merkle_verify_batch if arity == 2 else sharded.merkle_verify_arity4_batch)(
                     sel, idx, paths, depth, root)
@@ -137,7 +115,7 @@ def test_run_time_instances_through_many_chunks(A, R, oracle, staging):
     st = np.stack([enc(s) for s in st_i])
     msgs = np.random.default_rng(3).integers(0, 256, size=(n, 100), dtype=np.uint8)
     whole_p, whole_j, whole_h = gpu.permutation_batch(st), gpu.compress_k_batch(st, 2), gpu.hash_batch(msgs, w - 1)
-    with env(ANEMOI_CHUNK_TARGET_BYTES=1, ANEMOI_TEST_QUANTUM=64 * cols, ANEMOI_HOST_STAGING=staging):
+    with knobs(chunk_target_bytes=1, test_quantum=64 * cols, host_staging=staging):
         got_p, got_j, got_h = gpu.permutation_batch(st), gpu.compress_k_batch(st, 2), gpu.hash_batch(msgs, w - 1)
     assert (got_p == whole_p).all() and (got_j == whole_j).all() and (got_h == whole_h).all()
     for i in range(0, n, 97):
@@ -153,13 +131,13 @@ def test_run_time_instances_through_many_chunks(A, R, oracle, staging):
 
 
 def test_sponge_segments_without_pinned_staging(A, oracle):
-    """ANEMOI_HOST_STAGING=direct: the segment-fed sponge uploads each segment as one strided copy straight from
+    """host_staging=direct: the segment-fed sponge uploads each segment as one strided copy straight from
     the caller's memory instead of gathering into pinned staging (it used to ignore the knob, and to fail when
     pinning failed).  Same digests as the oracle."""
     rng = np.random.default_rng(5)
     fid, inst = FIELD_IDS.index("bn_254"), A.Anemoi("bn_254", 4)
     n, unit = 50, 3 * inst.chunk
     msgs = rng.integers(0, 256, size=(n, 7 * unit + 11), dtype=np.uint8)
-    with env(ANEMOI_SPONGE_SEGMENT_BYTES=n * unit * 2, ANEMOI_HOST_STAGING="direct"):
+    with knobs(sponge_segment_bytes=n * unit * 2, host_staging="direct"):
         got = inst.hash_batch(msgs)
     assert (got == oracle.hash_bytes_batch(fid, 4, msgs, threads=4)).all()

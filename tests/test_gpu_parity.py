@@ -10,7 +10,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import FIELD_IDS, INSTANCES, inst_key
+from conftest import FIELD_IDS, INSTANCES, inst_key, knobs
 
 pytestmark = pytest.mark.gpu
 
@@ -31,36 +31,16 @@ def rand_elems(oracle, fid, modulus, count, seed):
     return oracle.ints_to_mont(fid, [rng.randrange(modulus) for _ in range(count)])
 
 
-class knobs:
-    """kernel-selection knobs for the duration of a with-block (the library reads them at every call)"""
-
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.prev = {k: os.environ.get(k) for k in self.kv}
-        for k, v in self.kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = str(v)
-
-    def __exit__(self, *exc):
-        for k, v in self.prev.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
-# small batches take the cooperative latency kernels by default; "lane" forces the lane-private throughput kernels
-LATENCY_KERNELS = {"default": {}, "lane": {"ANEMOI_COOP_MAX": 0, "ANEMOI_COOP4_MAX": 0, "ANEMOI_COOP43_MAX": 0,
-                                           "ANEMOI_COOP_SPONGE_MAX": 0}}
+# small batches take the cooperative latency kernels by default -- the two-row fold kernels (coop2d.h) for Anemoi-2-1,
+# the row-cooperative scan kernels for 4-3; "row" switches the two-row kernels off (2-1 on the row-cooperative scan
+# kernels), "lane" forces the lane-private throughput kernels
+LATENCY_KERNELS = {"default": {}, "row": {"coop2d_max": 0}, "lane": {"coop_max": 0, "coop2d_max": 0, "coop4_max": 0, "coop43_max": 0,
+                                           "coop_sponge_max": 0, "coop_climb_max": 0}}
 
 
 # ---------------------------------------------------------------- (1) the reference's own KATs
 
-@pytest.mark.parametrize("kernels", ["default", "lane"])
+@pytest.mark.parametrize("kernels", ["default", "row", "lane"])
 @pytest.mark.parametrize("field,width", INSTANCES)
 def test_reference_kats(A, kats, field, width, kernels):
     with knobs(**LATENCY_KERNELS[kernels]):
@@ -105,7 +85,7 @@ def check_reference_kats(A, kats, field, width):
 
 # ---------------------------------------------------------------- (2) differential vs the oracle
 
-@pytest.mark.parametrize("kernels", ["default", "lane"])
+@pytest.mark.parametrize("kernels", ["default", "row", "lane"])
 @pytest.mark.parametrize("field,width", INSTANCES)
 def test_permutation_and_jive_vs_oracle(A, oracle, params, field, width, kernels):
     """batches of 1 .. 130 states: by default the row-cooperative kernels (k_jive2_coop / k_jive4_coop /
@@ -142,7 +122,7 @@ def check_permutation_and_jive_vs_oracle(A, oracle, params, field, width):
             assert (got[i] == oracle.merge(fid, width, pr[i, 0], pr[i, 1])).all()
 
 
-@pytest.mark.parametrize("kernels", ["default", "lane"])
+@pytest.mark.parametrize("kernels", ["default", "row", "lane"])
 @pytest.mark.parametrize("field,width", INSTANCES)
 def test_sponge_vs_oracle(A, oracle, params, field, width, kernels):
     """small batches: by default the row-cooperative sponge (k_sponge_coop), with "lane" the lane-private one"""
@@ -445,6 +425,25 @@ for fid, field in enumerate(A.FIELD_IDS):
         assert (got == oracle.compress_batch(fid, 2, st, threads=8)).all(), (field, n)
     leaves = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(64)])
     assert (A.Anemoi(field, 2).merkle_root(leaves, 6) == oracle.merkle_root(fid, leaves, 6)).all()
+    # the other Anemoi-2-1 latency kernels under the same forcing: permutation, sponge (bytes / elements), path climb
+    inst2 = A.Anemoi(field, 2)
+    st = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(2 * 5)]).reshape(5, 2, L)
+    pg = inst2.permutation_batch(st)
+    assert all((pg[i] == oracle.permutation(fid, 2, st[i])).all() for i in range(5)), field
+    for ln in (0, 1, inst2.chunk - 1, inst2.chunk, inst2.chunk + 1, 100):
+        msgs = np.frombuffer(rng.randbytes(3 * ln), dtype=np.uint8).reshape(3, ln) if ln else np.zeros((3, 0), dtype=np.uint8)
+        assert (inst2.hash_batch(msgs) == oracle.hash_bytes_batch(fid, 2, msgs, threads=1)).all(), (field, ln)
+    for ne in (0, 1, 2, 5):
+        el = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(3 * ne)]).reshape(3, ne, L)
+        assert (inst2.hash_field_batch(el) == oracle.hash_field_batch(fid, 2, el, threads=1)).all(), (field, ne)
+    tree = inst2.merkle_tree(leaves, 6)
+    idx = [0, 1, 37, 63]
+    paths = np.stack([inst2.merkle_path(tree, 6, i) for i in idx])
+    okv = inst2.merkle_verify_batch(leaves[idx], np.array(idx, dtype=np.uint64), paths, 6, tree[-1][0])
+    assert okv.all(), field
+    bad = leaves[idx].copy(); bad[2, 0] ^= np.uint64(1)
+    okv = inst2.merkle_verify_batch(bad, np.array(idx, dtype=np.uint64), paths, 6, tree[-1][0])
+    assert list(okv) == [True, True, False, True], field
     # Anemoi-4-3: the row-cooperative kernel (two states per wavefront) against the lane-pair kernel's oracle, k = 2 and 4
     for n in (1, 2, 3, 33, 130):
         st = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(4 * n)]).reshape(n, 4, L)
@@ -456,10 +455,13 @@ for fid, field in enumerate(A.FIELD_IDS):
             assert (got == oracle.compress_batch(fid, 4, st, k=k, threads=8)).all(), (field, n, k)
 print("ok")
 '''.replace("ROOT", repr(ROOT))
-    for coop_max, coop4_max, coop43_max in (("0", "0", "0"), ("1000000000", "0", "1000000000"), ("0", "1000000000", "1")):
-        env = dict(os.environ, ANEMOI_COOP_MAX=coop_max, ANEMOI_COOP4_MAX=coop4_max, ANEMOI_COOP43_MAX=coop43_max)
+    # (one-per-wavefront scan, two-row fold, row-cooperative scan 2-1, row-cooperative 4-3): each forced for every size
+    for coop_max, coop2d_max, coop4_max, coop43_max in (("0", "0", "0", "0"), ("1000000000", "0", "0", "1000000000"),
+                                                         ("0", "0", "1000000000", "1"), ("0", "1000000000", "0", "0")):
+        env = dict(os.environ, ANEMOI_COOP_MAX=coop_max, ANEMOI_COOP2D_MAX=coop2d_max, ANEMOI_COOP4_MAX=coop4_max,
+                   ANEMOI_COOP43_MAX=coop43_max)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-        assert out.returncode == 0 and "ok" in out.stdout, (coop_max, coop4_max, coop43_max, out.stdout[-1500:], out.stderr[-1500:])
+        assert out.returncode == 0 and "ok" in out.stdout, (coop_max, coop2d_max, coop4_max, coop43_max, out.stdout[-1500:], out.stderr[-1500:])
 
 
 def test_concurrent_callers(A, oracle, params):

@@ -53,7 +53,7 @@ for lg in sizes:
     torch.cuda.empty_cache()
     print("2^%d items: device-resident kernel %.2f ms = %.2f M/s" % (lg, resident, n / resident / 1e3))
     for mode in ("pinned", "direct"):
-        os.environ["ANEMOI_HOST_STAGING"] = mode
+        A.set_option("host_staging", mode)
         ts = []
         for _ in range(4):
             t0 = time.perf_counter()
@@ -64,7 +64,7 @@ for lg in sizes:
         t = median(ts[1:]) * 1e3
         print("  host-pointer, staging=%-6s: %.2f ms = %.2f M/s  -> %.3f x the resident rate (first call %.1f ms)"
               % (mode, t, n / t / 1e3, resident / t, ts[0] * 1e3))
-    os.environ.pop("ANEMOI_HOST_STAGING", None)
+    A.set_option("host_staging", None)
 
 # config 3 through the host-pointer entry point: 2^16 messages x 10 240 bytes (640 MiB) of pageable memory.  Too few
 # messages to cut into message chunks, so the library feeds them segment by segment (capi.hip sponge_segments).
@@ -89,7 +89,7 @@ if "cfg3" in sys.argv or len(sys.argv) == 1:
     print("config 3 (2^16 x 10 240 B, BN-254 4-3): device-resident kernel %.1f ms" % resident)
     for label, env in (("segments (default)", None), ("single launch", "1099511627776")):
         if env:
-            os.environ["ANEMOI_SPONGE_SEGMENT_BYTES"] = env   # one segment would hold everything -> single launch
+            A.set_option("sponge_segment_bytes", int(env))   # one segment would hold everything -> single launch
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
@@ -100,7 +100,7 @@ if "cfg3" in sys.argv or len(sys.argv) == 1:
         assert (dig == want).all()
         t = median(ts[1:]) * 1e3
         print("  host-pointer, %-18s: %.1f ms -> %.3f x the resident rate (first call %.1f ms)" % (label, t, resident / t, ts[0] * 1e3))
-    os.environ.pop("ANEMOI_SPONGE_SEGMENT_BYTES", None)
+    A.set_option("sponge_segment_bytes", None)
 
 # A 640 MiB ragged batch (2^19 BN-254 4-3 messages of 1 024 .. 1 536 bytes, unsorted) through
 # anemoi_hash_bytes_ragged_batch, which now runs on the chunked pipeline (chunks cut at message boundaries, offsets
@@ -130,7 +130,7 @@ if "ragged" in sys.argv or len(sys.argv) == 1:
     torch.cuda.empty_cache()
     print("ragged batch (2^19 messages, %.0f MiB, BN-254 4-3): device-resident kernel %.1f ms" % (blob.size / 2**20, resident))
     for mode in ("pinned", "direct"):
-        os.environ["ANEMOI_HOST_STAGING"] = mode
+        A.set_option("host_staging", mode)
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
@@ -141,7 +141,7 @@ if "ragged" in sys.argv or len(sys.argv) == 1:
         assert (dig == want).all()
         t = median(ts[1:]) * 1e3
         print("  host-pointer, staging=%-6s: %.1f ms -> %.3f x the resident rate (first call %.1f ms)" % (mode, t, resident / t, ts[0] * 1e3))
-    os.environ.pop("ANEMOI_HOST_STAGING", None)
+    A.set_option("host_staging", None)
     del blob, offs
 
 # 2^22 depth-24 authentication paths (Jubjub; 3.4 GB of host memory) through anemoi_merkle_verify_batch
@@ -171,7 +171,7 @@ if "verify" in sys.argv or len(sys.argv) == 1:
     print("path verification (2^22 paths of depth 24, Jubjub): device-resident kernel %.1f ms" % resident)
     ok = np.zeros(nv, dtype=np.uint8)
     for mode in ("pinned", "direct"):
-        os.environ["ANEMOI_HOST_STAGING"] = mode
+        A.set_option("host_staging", mode)
         ts = []
         for _ in range(2):
             t0 = time.perf_counter()
@@ -183,7 +183,7 @@ if "verify" in sys.argv or len(sys.argv) == 1:
         assert ok[12345] == 1 and ok.sum() == (roots == root).all(axis=1).sum()
         t = min(ts) * 1e3
         print("  host-pointer, staging=%-6s: %.1f ms -> %.3f x the resident rate (first call %.1f ms)" % (mode, t, resident / t, ts[0] * 1e3))
-    os.environ.pop("ANEMOI_HOST_STAGING", None)
+    A.set_option("host_staging", None)
     del leaves, paths, idx
 
 # concurrent callers: latency-bound calls (48 items = one wave-cooperative launch each) from 4 threads

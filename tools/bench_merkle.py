@@ -35,7 +35,7 @@ for _ in range(3):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(s); run_dev(); b.record(s); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
 root_dev = d_root.cpu().numpy().view(np.uint64)
-print("%s depth %d, device-resident, one stream (COOP_MAX=%s): %.2f ms" % (field, depth, os.environ.get("ANEMOI_COOP_MAX", "default"), sorted(ts)[1]))
+print("%s depth %d, device-resident, one stream (COOP_MAX=%s): %.2f ms" % (field, depth, A.get_option("coop_max"), sorted(ts)[1]))
 
 if len(sys.argv) > 3:  # per-level times: one launch per level, events around each
     pc = []
@@ -55,7 +55,7 @@ if len(sys.argv) > 3:  # per-level times: one launch per level, events around ea
 
 inst = A.Anemoi(field, 2, device=A.ALL_DEVICES)
 for parts in (1, 2, 4, 8, 16, 32):
-    os.environ["ANEMOI_VIRTUAL_DEVICES"] = str(parts)
+    A.set_option("virtual_devices", parts)
     inst.merkle_root(leaves, depth)
     ts = []
     for _ in range(3):
@@ -65,7 +65,7 @@ for parts in (1, 2, 4, 8, 16, 32):
 
 # the retained-level builder from host leaves (every level copied back to the caller's tree array)
 one = A.Anemoi(field, 2, device=0)
-os.environ.pop("ANEMOI_VIRTUAL_DEVICES", None)
+A.set_option("virtual_devices", None)
 one.merkle_tree(leaves, depth)
 ts = []
 for _ in range(3):

@@ -243,6 +243,78 @@ def check_schedule(e, k, first, steps, p):
     assert acc == pow(x, e, p)
 
 
+# ---- the two-row "fold" layout of csrc/coop2d.h (tools/coop2d_model.py is its executable specification) ------------
+FOLD_W = 28
+FOLD_SLACK = 34      # R'/p >= 2^34: a folded product of inputs < 2^35 p stays < 2^33 p
+
+
+class FoldLayout:
+    def __init__(self, p):
+        self.W = FOLD_W
+        self.NL = -(-(p.bit_length() + FOLD_SLACK) // self.W)
+        assert self.NL <= 15
+        self.Q = (self.NL + 1) // 2
+        self.OFF = 16 - self.NL
+        self.R = 1 << (self.W * self.NL)
+        self.M = (1 << self.W) - 1
+
+
+def fold_layout(p):
+    return FoldLayout(p)
+
+
+def fold_struct(fl, p, L, g, delta, i21, i43):
+    """struct Fold of FieldC: constants of the two-row cooperative arithmetic (W = 28, R' = 2^(28 NL), NL chosen so that
+    R'/p >= 2^34).  FoldT is the fold table in the kernels' lane order: word [(q * 2 + h) * 16 + l] = limb l of
+    C_(2q+h) = 2^(28 (2q+h)) R'^-1 mod p (0 beyond NL)."""
+    import math
+    W, NL, Q = fl.W, fl.NL, fl.Q
+    Rp = fl.R % p
+    rinv = pow(fl.R, -1, p)
+
+    def limbsw(v, n=NL):
+        assert 0 <= v < (1 << (W * n))
+        return [(v >> (W * i)) & fl.M for i in range(n)]
+
+    # g * x: limb-wise while g * (2^28 + 2^6) fits 32 bits, else a product by g R'.  What the S-box subtracts is
+    # g * (a product output) or a product output; product outputs are < 2^32.5 p (tools/coop2d_bounds.py walks the
+    # permutation with exact bounds and tests/test_coop2d_model.py runs it), so the subtraction pad is the next power
+    # of two above g * 2^32.5 (or above 2^32.5), and every difference is settled (multiplied by R' mod p) at once.
+    scale_g = g * ((1 << W) + 64) < (1 << 32)
+    subk = 1 << (math.ceil(math.log2(g) + 32.5) if scale_g else 33)
+    q = limbsw(subk * p)
+    kp = [q[0] + (1 << W)] + [q[i] + (1 << W) - 1 for i in range(1, NL - 1)] + [q[NL - 1] - 1]
+    assert sum(v << (W * i) for i, v in enumerate(kp)) == subk * p and all(0 <= v < (1 << (W + 1)) for v in kp)
+    assert (subk + (1 << 36)) * p < fl.R, "pad + operands must stay below R'"
+    s = []
+    s.append("  struct Fold {  // two-row cooperative layout (coop2d.h): radix 2^%d, %d limbs, R' = 2^%d, R'/p = 2^%.1f" % (
+        W, NL, W * NL, W * NL - math.log2(p)))
+    s.append("    static constexpr int W = %d, NL = %d, Q = %d, OFF = %d;" % (W, NL, Q, fl.OFF))
+    s.append("    static constexpr bool kScaleG = %s;  // g * x limb-wise (else a product by g R')" % ("true" if scale_g else "false"))
+    s.append("    static constexpr uint32_t kN0Inv = 0x%08xu;  // -p^-1 mod 2^W (mul_exact only)" % ((-pow(p, -1, 1 << W)) % (1 << W)))
+    for nm, v in (("P", p), ("One", Rp), ("RR", Rp * Rp % p),
+                  ("In", pow(2, 2 * W * NL - 64 * L, p)), ("Out", pow(2, 64 * L, p)),
+                  ("Delta", delta * Rp % p), ("GMont", g * Rp % p)):
+        s.append("    static constexpr uint32_t %s[%d] = %s;" % (nm, NL, c32(limbsw(v))))
+    s.append("    static constexpr uint32_t KP[%d] = %s;  // 2^%d p, limb-padded (subtraction pad)" % (
+        NL, c32(kp), subk.bit_length() - 1))
+    tab = []
+    for qq in range(Q):
+        for hh in range(2):
+            k = 2 * qq + hh
+            ck = ((1 << (W * k)) * rinv) % p if k < NL else 0
+            tab += limbsw(ck) + [0] * (16 - NL)
+    s.append("    static constexpr uint32_t FoldT[%d] = %s;" % (len(tab), c32(tab)))
+    for nm, inst in (("21", i21), ("43", i43)):
+        for cd in ("c", "d"):
+            vals = []
+            for v in inst["ark_" + cd]:
+                vals += limbsw(int(v) * Rp % p)
+            s.append("    static constexpr uint32_t Ark%s_%s[%d] = %s;" % (cd.upper(), nm, len(vals), c32(vals)))
+    s.append("  };")
+    return s
+
+
 def main():
     with open(os.path.join(ROOT, "tests", "golden", "params.json")) as f:
         params = json.load(f)
@@ -359,6 +431,7 @@ def main():
 
         h += radix_struct(29)
         h.append("  using Coop = R29;  // limb layout of the wave-cooperative kernels (coop29.h)")
+        h += fold_struct(fold_layout(p), p, L, g, delta, i21, i43)
         if p.bit_length() > 300:
             h += radix_struct(30)
             h.append("#if (ANEMOI_RADIX30_FIELDS >> %d) & 1" % fid)
