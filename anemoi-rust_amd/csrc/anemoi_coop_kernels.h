@@ -89,8 +89,7 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typ
       // the step's table operand is read from LDS BEFORE its squarings (a lone wavefront would otherwise sit out the
       // LDS latency in front of every multiplication)
       const uint32_t opnd = idx < 253 ? tab[idx * kBlock + lane] : 0u;
-#pragma nounroll
-      for (int q = 0; q < nsq; q++) acc = C::mul(acc, acc, k);
+      if (nsq) acc = C::sqr_n(acc, uint32_t(nsq), k);
       if (idx == 254) acc = C::mul(acc, tmp, k);
       else if (idx != 255) acc = C::mul(acc, opnd, k);
     }

@@ -32,6 +32,10 @@
 #include <type_traits>
 
 #include "field_consts_gen.h"
+#include "coop2d_asm_gen.h"   // tools/gen_coop2d_asm.py: the product below, hand-scheduled
+#ifndef ANEMOI_ASM_MUL
+#define ANEMOI_ASM_MUL 1
+#endif
 
 namespace anemoi {
 
@@ -42,7 +46,7 @@ struct Coop2d {
   static constexpr int NABI = F::N;
   static constexpr int kLanesPerItem = 32;   // two 16-lane rows
   static constexpr uint32_t MASK = (1u << W) - 1;
-  static_assert(W == 28 && NL <= 15 && OFF == 16 - NL && Q == (NL + 1) / 2, "layout of tools/coop2d_model.py");
+  static_assert((W == 27 || W == 28) && NL <= 15 && OFF == 16 - NL && Q == (NL + 1) / 2, "layout of tools/coop2d_model.py");
 
   // ---- DPP / cross-row primitives ---------------------------------------------------------------------------------
   template <int CTRL>
@@ -101,6 +105,7 @@ struct Coop2d {
   struct K {
     uint32_t pl, kpl, delta, one, gm, in, out, rr;
     uint32_t ct[Q];   // fold table: row h, lane l, step q holds limb l of C_(2q+h)
+    uint32_t mtop, only15;   // 15 limbs: the limb mask with lane 15 all ones; all ones in lane 15 only
   };
   __device__ static __forceinline__ K load_consts() {
     K k{konst(L::P), konst(L::KP), konst(L::Delta), konst(L::One), konst(L::GMont), konst(L::In), konst(L::Out),
@@ -108,6 +113,8 @@ struct Coop2d {
     const uint32_t h = odd_row() ? 1u : 0u;
 #pragma unroll
     for (int q = 0; q < Q; q++) k.ct[q] = L::FoldT[(q * 2 + h) * 16 + limb()];
+    k.mtop = limb() == 15 ? 0xffffffffu : MASK;
+    k.only15 = limb() == 15 ? 0xffffffffu : 0u;
     return k;
   }
 
@@ -144,6 +151,23 @@ struct Coop2d {
   // a * b * R'^-1 mod p, lazily: result < (A B / H + NL 2^W) p for a < A p, b < B p; limbs < 2^W + 2^5.
   // tools/coop2d_model.py::mul is this function lane for lane.
   __device__ static __forceinline__ uint32_t mul(uint32_t a, uint32_t b, const K& k) {
+#if ANEMOI_ASM_MUL
+    if constexpr (NL > 13) return AsmCoop2d<NL, W>::mul(a, b, k.ct, k.mtop, k.only15);
+    else return AsmCoop2d<NL, W>::mul(a, b, k.ct);
+#endif
+    return mul_cxx(a, b, k);
+  }
+  // x^(2^n), n >= 1: a run of squarings (the assembly keeps the loop inside one statement)
+  __device__ static __forceinline__ uint32_t sqr_n(uint32_t a, uint32_t n, const K& k) {
+#if ANEMOI_ASM_MUL
+    if constexpr (NL > 13) return AsmCoop2d<NL, W>::sqr_run(a, k.ct, k.mtop, k.only15, n);
+    else return AsmCoop2d<NL, W>::sqr_run(a, k.ct, n);
+#endif
+    for (uint32_t i = 0; i < n; i++) a = mul_cxx(a, a, k);
+    return a;
+  }
+  // the readable form of the same product (ANEMOI_ASM_MUL=0 builds run it)
+  __device__ static __forceinline__ uint32_t mul_cxx(uint32_t a, uint32_t b, const K& k) {
     const uint32_t aD = odd_rows_from_next(a), bS = odd_rows_from_prev(b);
     uint64_t LO = 0, HI = 0;
     static_for<0>([&](auto I) {   // P1
@@ -181,11 +205,20 @@ struct Coop2d {
       HI += (uint64_t)bcast<OFF + 2 * q>(tD) * k.ct[q];
     });
     // RN2
-    uint32_t hi, wh;
-    const uint32_t w2 = row_carry(HI, hi, wh);
-    const uint32_t y = pair_sum(w2);
-    // (lanes >= NL stay zero by themselves: no product or table entry reaches them and the value is far below R')
-    return (y & MASK) + from_prev(y >> W);
+    if constexpr (W <= 27) {   // the 64-bit sum over the rows first: <= 21 products of 2^54 leave a 32-bit carry
+      uint32_t l0 = (uint32_t)HI, h0 = (uint32_t)(HI >> 32), l1 = l0, h1 = h0;
+      swap16(l0, l1);
+      swap16(h0, h1);
+      const uint64_t tot = (((uint64_t)h0 << 32) | l0) + (((uint64_t)h1 << 32) | l1);
+      const uint32_t w = ((uint32_t)tot & MASK) + from_prev((uint32_t)(tot >> W));
+      return (w & MASK) + from_prev(w >> W);
+    } else {
+      uint32_t hi, wh;
+      const uint32_t w2 = row_carry(HI, hi, wh);
+      const uint32_t y = pair_sum(w2);
+      // (lanes >= NL stay zero by themselves: no product or table entry reaches them and the value is far below R')
+      return (y & MASK) + from_prev(y >> W);
+    }
   }
 
   // Digit-serial Montgomery product (the scan of coop29.h on this layout, both rows doing the same work): result

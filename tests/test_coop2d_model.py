@@ -1,0 +1,298 @@
+"""The two-row fold product (csrc/coop2d.h) on the CPU: (1) its executable specification tools/coop2d_model.py against
+big-integer arithmetic on random and adversarial limbs, with 32-/64-bit overflow checks at every step; (2) the
+GENERATED assembly (tools/gen_coop2d_asm.py -> csrc/coop2d_asm_gen.h) executed instruction by instruction on a 64-lane
+interpreter with the DPP controls, row / bank masks and v_permlane16_swap modelled -- multiplication and squaring runs,
+both layouts, two elements per wavefront that must not see each other; (3) the hazard distances of the emitted text
+re-checked independently of the generator's own padding; (4) the committed header is what the generator writes today.
+What a CPU cannot model is timing; what it can is every bit."""
+import os
+import random
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import coop2d_model as M  # noqa: E402
+import gen_coop2d_asm as G  # noqa: E402
+import gen_params as GP  # noqa: E402
+
+M32, M64 = (1 << 32) - 1, (1 << 64) - 1
+
+
+@pytest.fixture(scope="module")
+def moduli(params):
+    from conftest import FIELD_IDS
+    return {f: int(params[f]["modulus"]) for f in FIELD_IDS}
+
+
+def layouts(moduli):
+    return {f: M.Layout(p, GP.fold_w(p)) for f, p in moduli.items()}
+
+
+def operands(L, rng, bound_bits=35):
+    """limb lists a product may meet: all limbs at their maximum (2^W + 31), values next to the bound, p - 1, 0, random"""
+    bound = min(L.R - 1, (1 << bound_bits) * L.p)
+    full = [L.M + 32] * L.NL
+    full[-1] = min(bound >> (L.W * (L.NL - 1)), L.M + 32)
+    out = [full + [0] * (16 - L.NL), L.limbs(bound), L.limbs(L.p - 1), L.limbs(0), L.limbs(1)]
+    out += [L.limbs(rng.randrange(bound)) for _ in range(4)]
+    return out
+
+
+def test_model_against_big_integers(moduli):
+    """every field's layout: a b R'^-1 mod p at the value level, output limbs < 2^W + 2^5, nothing overflows for inputs
+    up to 2^35 p with every limb at its maximum"""
+    for f, L in layouts(moduli).items():
+        rng = random.Random(hash(f) & 0xffff)
+        assert L.H >= 1 << 34 and L.NL in (11, 15)
+        ops = operands(L, rng)
+        for a in ops:
+            for b in ops:
+                r = M.mul(L, a, b)
+                assert (L.value(r) * L.R - L.value(a) * L.value(b)) % L.p == 0, f
+                assert all(x <= L.M + 32 for x in r[:L.NL]) and all(x == 0 for x in r[L.NL:]), f
+                assert L.value(r) < (1 << 33) * L.p, f
+
+
+def test_model_notices_an_overflow(moduli):
+    """sanity of the checker: limbs twice as large as the layout allows must trip it"""
+    L = layouts(moduli)["bls12_381"]
+    big = [4 * L.M] * L.NL + [0]
+    with pytest.raises(M.Overflow):
+        M.mul(L, big, big)
+
+
+# ---- the generated assembly on a 64-lane interpreter ---------------------------------------------------------------------
+
+def parse_dpp(text):
+    ctrl = {"row_mask": 0xf, "bank_mask": 0xf, "bound": False, "kind": None, "n": 0}
+    for k in ("row_shr", "row_shl", "row_ror", "row_newbcast"):
+        m = re.search(k + r":(\d+)", text)
+        if m:
+            ctrl["kind"], ctrl["n"] = k, int(m.group(1))
+    for k in ("row_mask", "bank_mask"):
+        m = re.search(k + r":0x([0-9a-f]+)", text)
+        if m:
+            ctrl[k] = int(m.group(1), 16)
+    ctrl["bound"] = "bound_ctrl:1" in text
+    return ctrl
+
+
+def dpp_apply(old, src, ctrl, fn):
+    """new destination: fn(source lane value) in enabled lanes, `old` elsewhere"""
+    out = list(old)
+    for lane in range(64):
+        row, l = lane >> 4, lane & 15
+        if not (ctrl["row_mask"] >> row) & 1 or not (ctrl["bank_mask"] >> (l >> 2)) & 1:
+            continue
+        k, n = ctrl["kind"], ctrl["n"]
+        if k == "row_shr":
+            sl = l - n
+        elif k == "row_shl":
+            sl = l + n
+        elif k == "row_ror":
+            sl = (l - n) % 16
+        else:
+            sl = n
+        if 0 <= sl < 16:
+            out[lane] = fn(src[(row << 4) + sl], lane)
+        elif ctrl["bound"]:
+            out[lane] = fn(0, lane)
+    return out
+
+
+def run_asm(lines, opnd):
+    """opnd: {"%0": [64 values], ..., "%k": int for an SGPR}.  Returns the final %0."""
+    v, sreg = {}, {}
+    scc = 0
+
+    def get(tok):
+        tok = tok.strip()
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            lo, hi = v["v%s" % m.group(1)], v["v%d" % (int(m.group(1)) + 1)]
+            return [a | (b << 32) for a, b in zip(lo, hi)]
+        if tok in opnd:
+            x = opnd[tok]
+            return list(x) if isinstance(x, list) else [x] * 64
+        if tok.startswith("v"):
+            return list(v[tok])
+        return [int(tok, 0)] * 64
+
+    def put(tok, vals):
+        tok = tok.strip()
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            v["v%s" % m.group(1)] = [x & M32 for x in vals]
+            v["v%d" % (int(m.group(1)) + 1)] = [(x >> 32) & M32 for x in vals]
+        elif tok in opnd:
+            opnd[tok] = [x & M32 for x in vals]
+        else:
+            v[tok] = [x & M32 for x in vals]
+
+    labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
+    pc, steps = 0, 0
+    while pc < len(lines):
+        ln = lines[pc]
+        pc += 1
+        steps += 1
+        assert steps < 100000
+        if ln.endswith(":") or ln.startswith("s_nop"):
+            continue
+        op, _, rest = ln.partition(" ")
+        ctrl = None
+        m = re.search(r"\s(row_(?:shr|shl|ror|newbcast):.*)$", rest)
+        if m:
+            ctrl, rest = parse_dpp(m.group(1)), rest[:m.start()]
+        args = [x.strip() for x in re.split(r",\s*(?![^\[]*\])", rest)] if rest.strip() else []
+        if op == "s_sub_u32":
+            opnd[args[0]] = (opnd[args[1]] - int(args[2], 0)) & M32
+        elif op == "s_cmp_lg_u32":
+            scc = int(opnd[args[0]] != int(args[1], 0))
+        elif op == "s_cbranch_scc1":
+            if scc:
+                pc = labels[args[0][:-1]]       # "1b" -> label "1"
+        elif op == "v_mov_b32":
+            put(args[0], get(args[1]))
+        elif op == "v_mov_b32_dpp":
+            put(args[0], dpp_apply(get(args[0]) if args[0] in v or args[0] in opnd else [0] * 64, get(args[1]), ctrl, lambda s, lane: s))
+        elif op == "v_add_u32_dpp":
+            src1 = get(args[2])
+            old = get(args[0]) if args[0] in v or args[0] in opnd else [0] * 64
+            new = dpp_apply(old, get(args[1]), ctrl, lambda s, lane: s + src1[lane])
+            if max(new) > M32:
+                raise M.Overflow(ln)
+            put(args[0], new)
+        elif op == "v_add_u32":
+            s = [x + y for x, y in zip(get(args[1]), get(args[2]))]
+            if max(s) > M32:
+                raise M.Overflow(ln)
+            put(args[0], s)
+        elif op == "v_and_b32":
+            put(args[0], [x & y for x, y in zip(get(args[1]), get(args[2]))])
+        elif op == "v_lshrrev_b32":
+            put(args[0], [y >> (x & 31) for x, y in zip(get(args[1]), get(args[2]))])
+        elif op == "v_alignbit_b32":
+            hi, lo, sh = get(args[1]), get(args[2]), int(args[3], 0)
+            full = [((h << 32) | l) >> sh for h, l in zip(hi, lo)]
+            if max(full) > M32:
+                raise M.Overflow(ln)       # the kernel relies on the carry fitting 32 bits
+            put(args[0], full)
+        elif op == "v_mad_u64_u32":
+            s0, s1, s2 = get(args[2]), get(args[3]), get(args[4])
+            val = [x * y + z for x, y, z in zip(s0, s1, s2)]
+            if max(val) > M64:
+                raise M.Overflow(ln)
+            put(args[0], val)
+        elif op == "v_lshl_add_u64":
+            assert int(args[2], 0) == 0
+            val = [x + y for x, y in zip(get(args[1]), get(args[3]))]
+            if max(val) > M64:
+                raise M.Overflow(ln)
+            put(args[0], val)
+        elif op == "v_permlane16_swap_b32":
+            a, b = get(args[0]), get(args[1])
+            na, nb = list(a), list(b)
+            for pair in (0, 2):           # odd rows of vdst <-> even rows of src0
+                for l in range(16):
+                    na[((pair + 1) << 4) + l], nb[(pair << 4) + l] = b[(pair << 4) + l], a[((pair + 1) << 4) + l]
+            put(args[0], na)
+            put(args[1], nb)
+        else:
+            raise AssertionError("instruction not modelled: " + ln)
+    return opnd["%0"]
+
+
+def wave(rows):
+    """two elements per wavefront: element e on rows 2e and 2e+1 (both rows hold the same limbs)"""
+    return [rows[lane >> 5][lane & 15] for lane in range(64)]
+
+
+@pytest.mark.parametrize("field", ["jubjub", "bn_254", "ed_on_bls12_377", "vesta", "bls12_381", "bls12_377"])
+def test_generated_assembly_on_the_lane_interpreter(moduli, field):
+    L = layouts(moduli)[field]
+    rng = random.Random(7)
+    names_mul = G.operand_names(L.NL, False, False)
+    names_sqr = G.operand_names(L.NL, True, True)
+    mul_lines = G.gen_product(L.NL, L.W, False, False)[0]
+    sqr_lines = G.gen_product(L.NL, L.W, True, True)[0]
+    ct = [[(L.C[2 * q + ((lane >> 4) & 1)] >> (L.W * (lane & 15))) & L.M if (2 * q + ((lane >> 4) & 1) < L.NL and (lane & 15) < L.NL) else 0
+           for lane in range(64)] for q in range(L.Q)]
+    extra = {}
+    if L.NL > 13:
+        extra = {"MTOP": [0xffffffff if (lane & 15) == 15 else L.M for lane in range(64)],
+                 "ONLY15": [0xffffffff if (lane & 15) == 15 else 0 for lane in range(64)]}
+    ops = operands(L, rng)
+    for trial in range(12):
+        a2 = [ops[(trial * 3 + e) % len(ops)] for e in range(2)]          # the two elements of the wavefront differ
+        b2 = [ops[(trial * 5 + 2 * e + 1) % len(ops)] for e in range(2)]
+        opnd = {names_mul["A"]: wave(a2), names_mul["B"]: wave(b2)}
+        opnd.update({names_mul["CT"][q]: ct[q] for q in range(L.Q)})
+        opnd.update({names_mul[k]: val for k, val in extra.items()})
+        r = run_asm(mul_lines, opnd)
+        for e in range(2):
+            want = M.mul(L, a2[e], b2[e])          # the specification, limb for limb
+            for row in (2 * e, 2 * e + 1):
+                assert r[row * 16:(row + 1) * 16] == want, (field, trial, e, row)
+        # a run of n squarings = n products of the model
+        for n in (1, 3):
+            opnd = {names_sqr["A"]: wave(a2), names_sqr["CNT"]: n}
+            opnd.update({names_sqr["CT"][q]: ct[q] for q in range(L.Q)})
+            opnd.update({names_sqr[k]: val for k, val in extra.items()})
+            r = run_asm(sqr_lines, opnd)
+            for e in range(2):
+                want = a2[e]
+                for _ in range(n):
+                    want = M.mul(L, want, want)
+                assert r[(2 * e) * 16:(2 * e + 1) * 16] == want and r[(2 * e + 1) * 16:(2 * e + 2) * 16] == want, (field, trial, n, e)
+
+
+def test_hazard_distances_of_the_emitted_text():
+    """Independent of the generator's padding: a VGPR written by a VALU instruction is not read through DPP (source or
+    destination of a *_dpp instruction) or by v_permlane16_swap within the next two issue slots -- also across the
+    back-edge of the squaring loop (checked by unrolling the body twice)."""
+    for nl, W in G.LAYOUTS:
+        for square, loop in ((False, False), (True, True)):
+            lines = G.gen_product(nl, W, square, loop)[0]
+            if loop:
+                i0 = lines.index("1:")
+                i1 = next(i for i, l in enumerate(lines) if l.startswith("s_cbranch_scc1"))
+                lines = lines[:i0] + lines[i0 + 1:i1 + 1] + lines[i0 + 1:]
+            slot, wrote = 0, {}
+            for ln in lines:
+                op, _, rest = ln.partition(" ")
+                if op == "s_nop":
+                    slot += int(rest) + 1
+                    continue
+                if ln.endswith(":"):
+                    continue
+                regs = re.findall(r"v\[\d+:\d+\]|v\d+|%\d+", rest.split(" row_")[0])
+                flat = []
+                for r in regs:
+                    m = re.fullmatch(r"v\[(\d+):(\d+)\]", r)
+                    flat.append(["v%d" % i for i in range(int(m.group(1)), int(m.group(2)) + 1)] if m else [r])
+                sensitive = []
+                if op.endswith("_dpp"):
+                    sensitive = flat[0] + flat[1]            # destination (old value) and the DPP source
+                elif op.startswith("v_permlane16_swap"):
+                    sensitive = flat[0] + flat[1]
+                for r in sensitive:
+                    if r in wrote:
+                        assert slot - wrote[r] - 1 >= 2, (nl, square, ln, r)
+                if op.startswith("v_"):
+                    written = flat[0] + (flat[1] if op.startswith("v_permlane16_swap") else [])
+                    for r in written:
+                        wrote[r] = slot
+                slot += 1
+
+
+def test_committed_header_is_what_the_generator_writes():
+    import io
+    import contextlib
+    path = os.path.join(ROOT, "anemoi-rust_amd", "csrc", "coop2d_asm_gen.h")
+    before = open(path).read()
+    with contextlib.redirect_stdout(io.StringIO()):
+        G.main()
+    assert open(path).read() == before, "csrc/coop2d_asm_gen.h is stale: run tools/gen_coop2d_asm.py"

@@ -396,6 +396,45 @@ def test_concurrent_callers_overlap_on_the_gpu(A, oracle):
     assert conc < 0.6 * serial, (serial, conc)
 
 
+# ---------------------------------------------------------------- bench.py --gpus 2: the driver's N > 1 launch line
+
+def _bench_two_ranks(extra_env):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as a CHILD process (started before this
+    process's GPU state matters to it; nothing is exec'ed over a GPU-initialised process)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ANEMOI_BENCH_BACKEND", None)
+    env.pop("ANEMOI_BENCH_TEST_CORRUPT_RANK", None)
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo(A):
+    """The N > 1 branch of bench.py on the ONE GPU of a test box: two ranks under torch.distributed.run with the gloo
+    control plane (ANEMOI_BENCH_BACKEND=gloo; the ranks share device 0, so the TIME means nothing -- what is tested is
+    rank -> shard of config 4, the per-rank verification against the oracle goldens, the max-over-ranks and the JSON
+    line), then the same launch with one rank's output corrupted: no line, every rank exits non-zero."""
+    p = _bench_two_ranks({"ANEMOI_BENCH_BACKEND": "gloo"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["verified"]["ranks"] == 2 and line["verified"]["sha256_of_all_outputs"] is True
+    assert line["config"]["control_plane"] == "gloo" and line["config"]["parallelism"] == "shard2"
+    assert line["config"]["batch_per_gpu"] == 1 << 21 and line["scaling"] == "weak" and line["value"] > 0
+    assert "cpu_baseline" not in line          # rank 0 times the CPU baseline at N = 1 only
+    bad = _bench_two_ranks({"ANEMOI_BENCH_BACKEND": "gloo", "ANEMOI_BENCH_TEST_CORRUPT_RANK": "1"})
+    assert bad.returncode != 0, "a wrong shard on rank 1 must fail the whole run"
+    assert not [l for l in bad.stdout.splitlines() if l.startswith("{")], "no result line when a rank's output is wrong"
+    assert "rank 1" in bad.stderr
+
+
 # ---------------------------------------------------------------- bench.py --gpus 2 over RCCL (needs >= 2 GPUs)
 
 def test_bench_two_ranks_over_rccl(A):
@@ -403,21 +442,10 @@ def test_bench_two_ranks_over_rccl(A):
     one GPU each, each verifying its 2^21-item shard of config 4 against the oracle goldens.  Test boxes have one
     GPU, so this is skipped there -- NO hardware N > 1 number exists yet; the test is here so
     that the first multi-GPU box exercises the RCCL branch of bench.py before the driver's scaling run does."""
-    import socket
-    import subprocess
-    import sys
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("ANEMOI_BENCH_BACKEND", None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)   # a child process: no exec of this one
+    p = _bench_two_ranks({})
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["verified"]["ranks"] == 2 and line["verified"]["sha256_of_all_outputs"] is True

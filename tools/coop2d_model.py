@@ -12,7 +12,8 @@ wavefront: rows 0-1 and rows 2-3).  A product a * b * R'^-1 mod p  (R' = 2^(W NL
   P2   the low half is folded away with a table instead of two more products:
            T R'^-1 = TH + sum_k t_k C_k   (mod p),   C_k = 2^(W k) R'^-1 mod p,
        C_k[l] a per-lane constant, again split over the rows by parity and accumulated ONTO the HI accumulators;
-  RN2  HI is carried per row, summed over the rows and carried again: limbs < 2^W + 2^5, value < (AB/H + NL 2^W) p.
+  RN2  HI is carried per row, summed over the rows and carried again (W = 28), or summed over the rows as 64-bit values
+       and carried twice (W = 27): limbs < 2^W + 2^5, value < (AB/H + NL 2^W) p.
 
 No quotient digit, no digit-serial dependency: Q = ceil(NL / 2) multiply-add steps per phase instead of NL.
 This file is the executable specification: run() executes the exact lane program of the kernel on Python integers with
@@ -137,19 +138,30 @@ def mul(L, a, b, trace=None):
         CT = [[(L.C[2 * q + h] >> (W * l)) & M if (2 * q + h < NL and l < NL) else 0 for l in range(16)] for h in range(2)]
         HI = lanes(lambda acc, x, y: chk(acc + chk(x, 32, "t limb") * y, 64, "HI fold"), HI, Lq, CT)
     # RN2
-    lo = lanes(lambda x: x & M, HI)
-    hi = lanes(lambda x: chk(x >> W, 32, "HI >> W"), HI)
-    w = lanes(lambda x, y: chk(x + y, 32, "RN2 w"), lo, row_shr(hi, 1))
-    top = hi[0][15] + hi[1][15]
-    if top:
-        raise Overflow("carry out of the top limb")
-    wh = lanes(lambda x: x >> W, w)
-    w2 = lanes(lambda x, y: (x & M) + y, w, row_shr(wh, 1))
-    X = [list(w2[0]), list(w2[1])]
-    w2, X = swap16(w2, X)
-    y = lanes(lambda x, z: chk(x + z, 32, "RN2 y"), w2, X)
-    yh = lanes(lambda x: x >> W, y)
-    r = lanes(lambda x, z: (x & M) + z, y, row_shr(yh, 1))
+    if W <= 27:    # 64-bit sum over the rows first: <= 21 products of 2^54 leave a 32-bit carry
+        X = [list(HI[0]), list(HI[1])]
+        HIs, X = swap16(HI, X)
+        tot = lanes(lambda x, z: chk(x + z, 64, "RN2 total"), HIs, X)
+        hi = lanes(lambda x: chk(x >> W, 32, "total >> W"), tot)
+        if hi[0][15]:
+            raise Overflow("carry out of the top limb")
+        w = lanes(lambda x, y: chk((x & M) + y, 32, "RN2 w"), tot, row_shr(hi, 1))
+        wh = lanes(lambda x: x >> W, w)
+        r = lanes(lambda x, z: (x & M) + z, w, row_shr(wh, 1))
+    else:
+        lo = lanes(lambda x: x & M, HI)
+        hi = lanes(lambda x: chk(x >> W, 32, "HI >> W"), HI)
+        w = lanes(lambda x, y: chk(x + y, 32, "RN2 w"), lo, row_shr(hi, 1))
+        top = hi[0][15] + hi[1][15]
+        if top:
+            raise Overflow("carry out of the top limb")
+        wh = lanes(lambda x: x >> W, w)
+        w2 = lanes(lambda x, y: (x & M) + y, w, row_shr(wh, 1))
+        X = [list(w2[0]), list(w2[1])]
+        w2, X = swap16(w2, X)
+        y = lanes(lambda x, z: chk(x + z, 32, "RN2 y"), w2, X)
+        yh = lanes(lambda x: x >> W, y)
+        r = lanes(lambda x, z: (x & M) + z, y, row_shr(yh, 1))
     assert r[0] == r[1]
     if trace is not None:
         trace.update(LO=LO, HI=HI, t=t)

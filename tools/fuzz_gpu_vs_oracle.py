@@ -1,99 +1,153 @@
 #!/usr/bin/env python3
-"""One-off differential fuzz: many random and structured states per field through the GPU kernels
-(lane-private, row-cooperative and wave-cooperative Jive 2-1, Jive 4-3, permutation) against the C oracle.
-Structured states stress carry patterns: limbs of all ones, values next to p and to 2^k, sparse values.
-    python tools/fuzz_gpu_vs_oracle.py [items_per_field] [seed]"""
+"""Differential fuzz of EVERY kernel family against the C oracle: random and structured states per field through
+
+  Jive 2-1      lane-private, two-row fold (coop2d), row-cooperative scan, one-item-per-wavefront scan
+  Jive 4-3      lane-pair and row-cooperative, k = 2 and 4
+  permutation   the default routing of the batch size
+  sponge        two-row / row-cooperative / lane-private kernels on equal-length batches, the ragged kernel on all
+                lengths in one batch, the segment-fed host path (tiny forced segments)
+  generic       the run-time-instance kernels fed with the shipped constants (3 fields)
+
+Structured states stress carry patterns: limbs of all ones, values next to p and to 2^k, sparse values.  Kernels are
+forced through anemoi_set_option.  `run()` is what tests/test_gpu_fuzz.py calls (fixed seed, small sizes);
+
+    python tools/fuzz_gpu_vs_oracle.py [items_per_field] [seed]
+
+runs it big."""
+import json
 import os
 import random
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "anemoi-rust_amd")):
-    sys.path.insert(0, p)
-import json
+for _p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "anemoi-rust_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 import numpy as np
-import orc
-import anemoi_amd as A
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000   # > 8192: the lane-private kernel
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-params = json.load(open(os.path.join(ROOT, "tests", "golden", "params.json")))
-oracle = orc.Oracle()
-threads = 16
-bad = 0
-for fid, field in enumerate(A.FIELD_IDS):
-    p, L = int(params[field]["modulus"]), params[field]["u64_limbs"]
-    rng = random.Random(1000 * seed + fid)
-    vals = []
-    bits = p.bit_length()
+BIG = 1 << 40
+LANE = dict(coop_max=0, coop2d_max=0, coop4_max=0, coop43_max=0, coop_sponge_max=0, coop_climb_max=0)
+
+
+def structured_values(p):
+    vals, bits = [], p.bit_length()
     for k in range(0, bits, 7):
         for d in (-2, -1, 0, 1, 2):
             vals.append(((1 << k) + d) % p)
             vals.append((p - (1 << k) + d) % p)
     vals += [((1 << bits) - 1) % p, (1 << (bits - 1)) % p, p - 1, p - 2, 0, 1, 2]
-    for w in (29, 30, 32, 58, 60, 64):
+    for w in (28, 29, 30, 32, 56, 58, 60, 64):
         ones = 0
         for i in range(0, bits, 2 * w):
             ones |= ((1 << w) - 1) << i
         vals += [ones % p, (ones << w) % p]
-    structured = vals
-    for width in (2, 4):
-        cnt = n if width == 2 else n // 4
-        items = []
-        for i in range(cnt):
-            if i < len(structured):
-                st = [structured[(i + j * 17) % len(structured)] for j in range(width)]
+    return vals
+
+
+def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
+    """Returns the list of failed checks (empty = all bit-exact)."""
+    import orc
+    import anemoi_amd as A
+    params = json.load(open(os.path.join(ROOT, "tests", "golden", "params.json")))
+    oracle = orc.Oracle()
+    failed = []
+
+    def check(ok, what):
+        if not ok:
+            failed.append(what)
+        return "ok" if ok else "MISMATCH"
+
+    for fid, field in enumerate(A.FIELD_IDS):
+        p, L = int(params[field]["modulus"]), params[field]["u64_limbs"]
+        rng = random.Random(1000 * seed + fid)
+        structured = structured_values(p)
+        for width in (2, 4):
+            cnt = n2 if width == 2 else n4
+            items = []
+            for i in range(cnt):
+                if i < len(structured):
+                    items.extend(structured[(i + j * 17) % len(structured)] for j in range(width))
+                else:
+                    items.extend(rng.randrange(p) for _ in range(width))
+            st = oracle.ints_to_mont(fid, items).reshape(cnt, width, L)
+            inst = A.Anemoi(field, width)
+            exp = oracle.compress_batch(fid, width, st, threads=threads)
+            msg = "%-16s W=%d %6d items:" % (field, width, cnt)
+            if width == 2:
+                with A.options(**LANE):
+                    msg += " lane-private %s" % check((inst.compress_batch(st) == exp).all(), (field, width, "lane-private"))
+                m = min(cnt, 1501)
+                with A.options(coop_max=0, coop2d_max=BIG, coop4_max=0):
+                    msg += "  two-row(%d) %s" % (m, check((inst.compress_batch(st[:m]) == exp[:m]).all(), (field, width, "two-row")))
+                m = min(cnt, 3001)
+                with A.options(coop_max=0, coop2d_max=0, coop4_max=BIG):
+                    msg += "  row-coop(%d) %s" % (m, check((inst.compress_batch(st[:m]) == exp[:m]).all(), (field, width, "row-coop")))
+                m = min(cnt, 300)
+                with A.options(coop_max=BIG, coop2d_max=0, coop4_max=0):
+                    msg += "  wave-coop(%d) %s" % (m, check((inst.compress_batch(st[:m]) == exp[:m]).all(), (field, width, "wave-coop")))
             else:
-                st = [rng.randrange(p) for _ in range(width)]
-            items.extend(st)
-        st = oracle.ints_to_mont(fid, items).reshape(cnt, width, L)
-        inst = A.Anemoi(field, width)
-        exp = oracle.compress_batch(fid, width, st, threads=threads)
-        got = inst.compress_batch(st)
-        ok = (got == exp).all()
-        msg = "%-16s W=%d compress %6d items: %s" % (field, width, cnt, "ok" if ok else "MISMATCH")
-        if width == 2:  # the latency kernels on slices (the selection knobs are read at every call)
-            ok2 = (inst.compress_batch(st[:3001]) == exp[:3001]).all()  # <= 8192 -> row-cooperative kernel, 4 items per wavefront
-            os.environ["ANEMOI_COOP_MAX"] = "1000000"
-            ok4 = (inst.compress_batch(st[:700]) == exp[:700]).all()    # forced: one item per wavefront
-            del os.environ["ANEMOI_COOP_MAX"]
-            msg += "  row-coop(3001): %s  wave-coop(700): %s" % ("ok" if ok2 else "MISMATCH", "ok" if ok4 else "MISMATCH")
-            ok = ok and ok2 and ok4
-        else:  # Anemoi-4-3: a slice small enough for the row-cooperative kernel (two states per wavefront), k = 2 and 4
-            ok2 = (inst.compress_batch(st[:1501]) == exp[:1501]).all()
-            ok4 = (inst.compress_k_batch(st[:1501], 4) == oracle.compress_batch(fid, 4, st[:1501], k=4, threads=threads)).all()
-            msg += "  row-coop(1501): k=2 %s k=4 %s" % ("ok" if ok2 else "MISMATCH", "ok" if ok4 else "MISMATCH")
-            ok = ok and ok2 and ok4
-        pg = inst.permutation_batch(st[:256])
-        ok3 = all((pg[i] == oracle.permutation(fid, width, st[i])).all() for i in range(0, 256, 5))
-        msg += "  permutation: %s" % ("ok" if ok3 else "MISMATCH")
-        print(msg, flush=True)
-        bad += 0 if (ok and ok3) else 1
-# sponge: random byte messages of structured lengths (around the chunk and rate-block boundaries) through the
-# row-cooperative sponge (small equal-length batches), the lane-private sponge (forced) and the ragged kernel
-nprng = np.random.default_rng(seed)
-for fid, field in enumerate(A.FIELD_IDS):
-    for width in (2, 4):
-        inst = A.Anemoi(field, width)
-        ch, r = inst.chunk, width - 1
-        lens = sorted({0, 1, ch - 1, ch, ch + 1, r * ch, r * ch + 1, 2 * r * ch - 1, 5 * ch + 3, 333} |
-                      {int(v) for v in nprng.integers(0, 400, size=6)})
-        ok = True
-        ragged, want = [], []
-        for ln in lens:
-            msgs = nprng.integers(0, 256, size=(9, ln), dtype=np.uint8)
-            if ln:
-                msgs[0], msgs[1] = 0, 255
-            exp = oracle.hash_bytes_batch(fid, width, msgs, threads=threads)
-            ok = ok and (inst.hash_batch(msgs) == exp).all()                      # cooperative sponge
-            os.environ["ANEMOI_COOP_SPONGE_MAX"] = "0"
-            ok = ok and (inst.hash_batch(msgs) == exp).all()                      # lane-private sponge
-            del os.environ["ANEMOI_COOP_SPONGE_MAX"]
-            ragged += [m.tobytes() for m in msgs]
-            want.append(exp)
-        ok = ok and (inst.hash_ragged(ragged) == np.concatenate(want)).all()      # ragged kernel, all lengths in one batch
-        print("%-16s W=%d sponge, %d lengths x 9 messages (cooperative, lane-private, ragged): %s"
-              % (field, width, len(lens), "ok" if ok else "MISMATCH"), flush=True)
-        bad += 0 if ok else 1
-print("FUZZ", "FAILED" if bad else "PASSED")
-sys.exit(1 if bad else 0)
+                exp4 = oracle.compress_batch(fid, 4, st, k=4, threads=threads)
+                with A.options(**LANE):
+                    ok = (inst.compress_batch(st) == exp).all() and (inst.compress_k_batch(st, 4) == exp4).all()
+                msg += " lane-pair %s" % check(ok, (field, width, "lane-pair"))
+                m = min(cnt, 1501)
+                with A.options(coop43_max=BIG):
+                    ok = (inst.compress_batch(st[:m]) == exp[:m]).all() and (inst.compress_k_batch(st[:m], 4) == exp4[:m]).all()
+                msg += "  row-coop(%d) k=2,4 %s" % (m, check(ok, (field, width, "row-coop 4-3")))
+            m = min(cnt, 256)
+            pg = inst.permutation_batch(st[:m])
+            ok = all((pg[i] == oracle.permutation(fid, width, st[i])).all() for i in range(0, m, 5))
+            msg += "  permutation %s" % check(ok, (field, width, "permutation"))
+            log(msg)
+    # sponge: random byte messages of structured lengths (around the chunk and rate-block boundaries)
+    nprng = np.random.default_rng(seed)
+    for fid, field in enumerate(A.FIELD_IDS):
+        for width in (2, 4):
+            inst = A.Anemoi(field, width)
+            ch, r = inst.chunk, width - 1
+            lens = sorted({0, 1, ch - 1, ch, ch + 1, r * ch, r * ch + 1, 2 * r * ch - 1, 5 * ch + 3, 333} |
+                          {int(v) for v in nprng.integers(0, 400, size=3)})
+            ok = True
+            ragged, want = [], []
+            for ln in lens:
+                msgs = nprng.integers(0, 256, size=(5, ln), dtype=np.uint8)
+                if ln:
+                    msgs[0], msgs[1] = 0, 255
+                exp = oracle.hash_bytes_batch(fid, width, msgs, threads=threads)
+                ok = ok and (inst.hash_batch(msgs) == exp).all()                      # default: two-row (2-1) / row-coop (4-3)
+                with A.options(coop2d_max=0):
+                    ok = ok and (inst.hash_batch(msgs) == exp).all()                  # row-cooperative sponge
+                with A.options(**LANE):
+                    ok = ok and (inst.hash_batch(msgs) == exp).all()                  # lane-private sponge
+                if ln > 3 * r * ch:
+                    with A.options(sponge_segment_bytes=5 * r * ch):                   # segment-fed host path
+                        ok = ok and (inst.hash_batch(msgs) == exp).all()
+                ragged += [m.tobytes() for m in msgs]
+                want.append(exp)
+            ok = ok and (inst.hash_ragged(ragged) == np.concatenate(want)).all()      # ragged kernel, all lengths in one batch
+            log("%-16s W=%d sponge, %d lengths x 5 messages (default, row-coop, lane-private, segments, ragged): %s"
+                % (field, width, len(lens), check(ok, (field, width, "sponge"))))
+    if generic:   # the run-time-instance kernels fed with the shipped constants reproduce the fixed instances
+        for field in ("bn_254", "bls12_381", "ed_on_bls12_377"):
+            fid = A.FIELD_IDS.index(field)
+            p, L = int(params[field]["modulus"]), params[field]["u64_limbs"]
+            rng = random.Random(77 * seed + fid)
+            for width, key in ((2, "anemoi_2_1"), (4, "anemoi_4_3")):
+                ins = params[field]["instances"][key]
+                c = width // 2
+                enc = lambda vals: oracle.ints_to_mont(fid, [int(v) for v in vals])
+                g = A.GenericAnemoi(field, c, ins["num_rounds"], enc(ins["ark_c"]), enc(ins["ark_d"]))
+                st = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(width * 70)]).reshape(70, width, L)
+                ok = (g.compress_k_batch(st, 2) == oracle.compress_batch(fid, width, st, threads=threads)).all()
+                log("%-16s W=%d generic (run-time instance) Jive: %s" % (field, width, check(ok, (field, width, "generic"))))
+    return failed
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000   # > 8192: the lane-private kernel at its real grid
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    bad = run(n2=n, n4=n // 4, seed=seed, log=lambda m: print(m, flush=True))
+    print("FUZZ %s in %.1f s" % ("FAILED: %r" % bad if bad else "PASSED", time.time() - t0))
+    sys.exit(1 if bad else 0)

@@ -244,13 +244,19 @@ def check_schedule(e, k, first, steps, p):
 
 
 # ---- the two-row "fold" layout of csrc/coop2d.h (tools/coop2d_model.py is its executable specification) ------------
-FOLD_W = 28
 FOLD_SLACK = 34      # R'/p >= 2^34: a folded product of inputs < 2^35 p stays < 2^33 p
+
+
+def fold_w(p):
+    """27-bit limbs for the 253..255-bit fields (11 limbs either way, and the 21 products of a result column then
+    leave a 32-bit carry, so the last carry pass can start from the 64-bit sum over the rows); 28 for the 377/381-bit
+    fields (15 limbs: 27 bits would need 16)"""
+    return 27 if p.bit_length() <= 256 else 28
 
 
 class FoldLayout:
     def __init__(self, p):
-        self.W = FOLD_W
+        self.W = fold_w(p)
         self.NL = -(-(p.bit_length() + FOLD_SLACK) // self.W)
         assert self.NL <= 15
         self.Q = (self.NL + 1) // 2
