@@ -78,19 +78,25 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typ
       tab[i * kBlock + lane] = pw;
     }
     uint32_t acc = tab[pc.first5 * kBlock + lane], tmp = acc;
+    // A lone wavefront pays every instruction between two products, so the step loop is kept lean: the NEXT step's
+    // schedule word is fetched (scalar load) before this step's products, the table operand is read from LDS before
+    // the squarings (clamped instead of branched around for the "no multiplication" step), and the tmp-register
+    // operations of the leading-run doubling exist only for the fields whose schedule uses them (Pallas / Vesta).
+    uint32_t word = uniform_word(pc.sched5, 0);
 #pragma nounroll
     for (int s = 0; s < pc.steps5; s++) {
-      const uint32_t word = uniform_word(pc.sched5, s);
-      const int nsq = word & 0xff, idx = word >> 8;
-      if (idx == 253) {  // leading-run doubling, see sliding_window() in tools/gen_params.py
-        tmp = acc;
-        continue;
+      const uint32_t next = uniform_word(pc.sched5, s + 1);   // (one word past the end on the last step: inside the blob)
+      const uint32_t nsq = word & 0xff, idx = word >> 8;
+      word = next;
+      if constexpr (F::kChainTmp) {
+        if (idx == 253) {  // leading-run doubling, see sliding_window() in tools/gen_params.py
+          tmp = acc;
+          continue;
+        }
       }
-      // the step's table operand is read from LDS BEFORE its squarings (a lone wavefront would otherwise sit out the
-      // LDS latency in front of every multiplication)
-      const uint32_t opnd = idx < 253 ? tab[idx * kBlock + lane] : 0u;
-      if (nsq) acc = C::sqr_n(acc, uint32_t(nsq), k);
-      if (idx == 254) acc = C::mul(acc, tmp, k);
+      const uint32_t opnd = tab[(idx < uint32_t(E) ? idx : 0u) * kBlock + lane];
+      if (nsq) acc = C::sqr_n(acc, nsq, k);
+      if (F::kChainTmp && idx == 254) acc = C::mul(acc, tmp, k);
       else if (idx != 255) acc = C::mul(acc, opnd, k);
     }
     t = acc;

@@ -1005,29 +1005,56 @@ int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t* msgs, co
     return with_lane(dev, [&](Lane& ln) -> int {
       const uint64_t* off = offsets + first;
       const size_t quantum = quantum_of(field, anemoi::kKindSponge, width, dev);
+      // Length bucketing: a wavefront costs what its longest message costs, and a realistic ragged batch arrives
+      // unsorted.  The host walks every offset anyway, so messages are STAGED by descending block count (stable;
+      // host::ragged_order returns nothing when the order as given is already within ~3 % of that) and the digests
+      // are scattered back to the caller's order: per-message semantics unchanged (src/<f>/anemoi_x/hasher.rs hash()).
+      const std::vector<size_t> order =
+          host::ragged_order(off, count, size_t(width - 1) * size_t(anemoi::field_ops(field)->chunk), per_wave);
+      std::vector<uint64_t> poff;     // offsets of the permuted sequence (virtual: the bytes are gathered while staging)
+      if (!order.empty()) {
+        poff.resize(count + 1);
+        poff[0] = 0;
+        for (size_t i = 0; i < count; i++) poff[i + 1] = poff[i] + (off[order[i] + 1] - off[order[i]]);
+      }
+      const uint64_t* voff = order.empty() ? off : poff.data();
       // at least half a wave of workgroups of messages per chunk (two chunks' kernels run side by side on the
       // lane's two kernel streams), at most 8 chunk targets of bytes
       const size_t target = rt::chunk_target_bytes();
       const std::vector<size_t> cuts =
-          host::plan_ragged_chunks(off, count, target, per_wave, quantum / 2, 4 * quantum, 8 * target);
+          host::plan_ragged_chunks(voff, count, target, per_wave, quantum / 2, 4 * quantum, 8 * target);
       auto cnt_of = [&](size_t c) { return cuts[c + 1] - cuts[c]; };
       auto off_bytes = [&](size_t c) { return align_up((cnt_of(c) + 1) * 8, 256); };
-      auto msg_bytes = [&](size_t c) { return size_t(off[cuts[c + 1]] - off[cuts[c]]); };
+      auto msg_bytes = [&](size_t c) { return size_t(voff[cuts[c + 1]] - voff[cuts[c]]); };
       return rt::pipeline_staged(
           ln, cuts.size() - 1,
           [&](size_t c) { return rt::StagedChunk{off_bytes(c) + msg_bytes(c) + 16, cnt_of(c) * eb, 0}; },
           [&](size_t c, char* h) -> int {
             uint64_t* rel = (uint64_t*)h;
-            const uint64_t base = off[cuts[c]];
-            for (size_t i = 0; i <= cnt_of(c); i++) rel[i] = off[cuts[c] + i] - base;
-            if (msg_bytes(c)) memcpy(h + off_bytes(c), msgs + base, msg_bytes(c));
+            const uint64_t base = voff[cuts[c]];
+            for (size_t i = 0; i <= cnt_of(c); i++) rel[i] = voff[cuts[c] + i] - base;
+            if (order.empty()) {
+              if (msg_bytes(c)) memcpy(h + off_bytes(c), msgs + base, msg_bytes(c));
+            } else {   // gather: message order[k] goes where the permuted sequence puts it
+              char* dst = h + off_bytes(c);
+              for (size_t i = 0; i < cnt_of(c); i++) {
+                const size_t m = order[cuts[c] + i];
+                const size_t len = size_t(off[m + 1] - off[m]);
+                if (len) memcpy(dst + rel[i], msgs + off[m], len);
+              }
+            }
             return ANEMOI_OK;
           },
           [&](size_t c, void* di, void* dout, void*, hipStream_t st) -> int {
             return anemoi_hash_bytes_ragged_dev(field, width, (char*)di + off_bytes(c), di, cnt_of(c), dout, st);
           },
           [&](size_t c, const char* h) -> int {
-            memcpy((char*)out + (first + cuts[c]) * eb, h, cnt_of(c) * eb);
+            if (order.empty()) {
+              memcpy((char*)out + (first + cuts[c]) * eb, h, cnt_of(c) * eb);
+            } else {
+              for (size_t i = 0; i < cnt_of(c); i++)
+                memcpy((char*)out + (first + order[cuts[c] + i]) * eb, h + i * eb, eb);
+            }
             return ANEMOI_OK;
           });
     });

@@ -9,6 +9,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 namespace anemoi {
@@ -129,6 +130,34 @@ inline std::vector<size_t> plan_ragged_chunks(const uint64_t* off, size_t n, siz
   }
   cuts.push_back(n);
   return cuts;
+}
+
+// Order in which a ragged batch should be fed to the sponge kernels: every lane of a wavefront walks its own message
+// and the wavefront runs as many rate-blocks as its LONGEST message, so `per_wave` consecutive messages should have
+// the same block count.  Returns the message indices by descending block count (stable) -- or an empty vector when the
+// given order already wastes less than 1/32 of the block-steps (sorted input, equal lengths, tiny batches).
+//   off[0..n]      message i = bytes [off[i], off[i+1])
+//   block_bytes    input bytes one permutation absorbs (RATE x chunk bytes)
+inline std::vector<size_t> ragged_order(const uint64_t* off, size_t n, size_t block_bytes, size_t per_wave) {
+  std::vector<size_t> order;
+  if (n <= per_wave || block_bytes == 0 || per_wave == 0) return order;
+  auto blocks = [&](size_t i) { return size_t((off[i + 1] - off[i] + block_bytes - 1) / block_bytes) + 1; };  // + the final permutation
+  // block-steps as given (sum over wavefronts of the longest message) against the minimum (the sorted order's)
+  unsigned long long given = 0, total = 0;
+  for (size_t w = 0; w < n; w += per_wave) {
+    size_t mx = 0, cnt = 0;
+    for (size_t i = w; i < n && i < w + per_wave; i++, cnt++) {
+      const size_t b = blocks(i);
+      mx = b > mx ? b : mx;
+      total += b;
+    }
+    given += (unsigned long long)mx * cnt;   // (the idle lanes of a partly filled last wavefront are nobody's fault)
+  }
+  if (given - total <= given / 32) return order;   // at most ~3 % of the lanes' block-steps idle: leave it
+  order.resize(n);
+  for (size_t i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return blocks(a) > blocks(b); });
+  return order;
 }
 
 // ---- the reference's hard-coded mds_layer arms as small-integer matrices --------------------------

@@ -523,6 +523,8 @@ struct StagedChunk {
   size_t in_bytes, out_bytes, tmp_bytes;
 };
 
+inline void quiesce(Lane& ln);
+
 template <class Plan, class Stage, class Launch, class Finish>
 int pipeline_staged(Lane& ln, size_t chunks, Plan plan, Stage stage, Launch launch, Finish finish) {
   if (chunks == 0) return ANEMOI_OK;
@@ -536,6 +538,16 @@ int pipeline_staged(Lane& ln, size_t chunks, Plan plan, Stage stage, Launch laun
   const int ns = chunks < size_t(kSlots) ? int(chunks) : kSlots;
   bool pinned = staging_mode() == 1;
   std::vector<char> pg_in[kSlots], pg_out[kSlots];  // pageable stand-ins for the pinned staging
+  // The stand-ins are locals while asynchronous copies may still read / write them when a stage / launch / finish or
+  // a HIP call fails half-way: every early return below first waits for the lane's streams (declared after the
+  // vectors, so it runs before they are freed).  With pinned staging the buffers belong to the lane and outlive this.
+  struct QuiesceBeforeFree {
+    Lane& ln;
+    bool armed = false;
+    ~QuiesceBeforeFree() {
+      if (armed) quiesce(ln);
+    }
+  } guard{ln};
   if (chunks > 1) {
     int rc = ln.pipeline_streams();
     if (rc) return rc;
@@ -551,8 +563,10 @@ int pipeline_staged(Lane& ln, size_t chunks, Plan plan, Stage stage, Launch laun
       for (auto& s2 : ln.slot) s2.p_in.release(), s2.p_out.release();
     }
   }
-  if (!pinned)
+  if (!pinned) {
     for (int i = 0; i < ns; i++) pg_in[i].resize(max_in ? max_in : 1), pg_out[i].resize(max_out ? max_out : 1);
+    guard.armed = true;
+  }
   auto host_in = [&](int i) { return pinned ? (char*)ln.slot[i].p_in.p : pg_in[i].data(); };
   auto host_out = [&](int i) { return pinned ? (char*)ln.slot[i].p_out.p : pg_out[i].data(); };
   const bool single = chunks == 1;
@@ -593,6 +607,7 @@ int pipeline_staged(Lane& ln, size_t chunks, Plan plan, Stage stage, Launch laun
   if (rc) return rc;
   for (size_t c = chunks > size_t(ns) ? chunks - ns : 0; c < chunks; c++)
     if ((rc = drain(c))) return rc;
+  guard.armed = false;   // every copy has been waited for (drain synchronises on each slot's copy-out event)
   return ANEMOI_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #include "../../anemoi-rust_amd/csrc/host_logic.h"
@@ -148,6 +149,62 @@ static void test_ragged_chunks() {
   }
 }
 
+static void test_ragged_order() {
+  // the order is a permutation by descending block count, stable, and is only produced when it pays
+  uint64_t seed = 99;
+  auto rnd = [&]() { seed = seed * 6364136223846793005ull + 1442695040888963407ull; return seed >> 33; };
+  for (int trial = 0; trial < 300; trial++) {
+    const size_t n = rnd() % 700, per_wave = (rnd() % 2) ? 64 : 32, block = 31 * (1 + rnd() % 3);
+    std::vector<uint64_t> off(n + 1, 0);
+    const unsigned shape = rnd() % 4;   // 0: equal lengths, 1: already sorted, 2: long-tailed, 3: uniform
+    for (size_t i = 0; i < n; i++) {
+      uint64_t len = shape == 0 ? 500 : shape == 2 ? (rnd() % 16 == 0 ? rnd() % 20000 : rnd() % 300) : rnd() % 3000;
+      off[i + 1] = off[i] + len;
+    }
+    if (shape == 1) {
+      std::vector<uint64_t> lens(n);
+      for (size_t i = 0; i < n; i++) lens[i] = off[i + 1] - off[i];
+      std::sort(lens.begin(), lens.end(), [](uint64_t a, uint64_t b) { return a > b; });
+      for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + lens[i];
+    }
+    auto blocks = [&](size_t i) { return (off[i + 1] - off[i] + block - 1) / block + 1; };
+    const std::vector<size_t> order = ragged_order(off.data(), n, block, per_wave);
+    auto cost = [&](const std::vector<size_t>& ord) {
+      unsigned long long c = 0;
+      for (size_t w = 0; w < n; w += per_wave) {
+        uint64_t mx = 0;      // a wavefront runs as many block-steps as its longest message, however many lanes are live
+        for (size_t i = w; i < n && i < w + per_wave; i++) mx = std::max<uint64_t>(mx, blocks(ord[i]));
+        c += mx;
+      }
+      return c;
+    };
+    std::vector<size_t> ident(n);
+    for (size_t i = 0; i < n; i++) ident[i] = i;
+    if (order.empty()) {
+      // left alone: the live lanes of the given order idle for at most 1/32 of their block-steps, or there is at most
+      // one wavefront
+      unsigned long long total = 0, given = 0;
+      for (size_t w = 0; w < n; w += per_wave) {
+        uint64_t mx = 0, cnt = 0;
+        for (size_t i = w; i < n && i < w + per_wave; i++, cnt++) mx = std::max<uint64_t>(mx, blocks(i)), total += blocks(i);
+        given += mx * cnt;
+      }
+      CHECK(n <= per_wave || given - total <= given / 32);
+      if (shape == 0 || shape == 1) continue;
+    } else {
+      CHECK(order.size() == n);
+      std::vector<char> seen(n, 0);
+      for (size_t i = 0; i < n; i++) {
+        CHECK(order[i] < n && !seen[order[i]]);
+        seen[order[i]] = 1;
+        if (i) CHECK(blocks(order[i - 1]) > blocks(order[i]) || (blocks(order[i - 1]) == blocks(order[i]) && order[i - 1] < order[i]));
+      }
+      CHECK(cost(order) <= cost(ident));
+      CHECK(shape != 0);   // equal lengths are never reordered
+    }
+  }
+}
+
 static void test_mds_and_k() {
   std::vector<uint64_t> m;
   CHECK(!builtin_mds(0, 2, &m) && !builtin_mds(7, 2, &m));
@@ -184,6 +241,7 @@ int main() {
   test_paths();
   test_overlap_and_chunks();
   test_ragged_chunks();
+  test_ragged_order();
   test_mds_and_k();
   std::printf("host logic ok\n");
   return 0;

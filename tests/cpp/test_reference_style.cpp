@@ -172,6 +172,43 @@ int main(int argc, char** argv) {
     auto mb4 = I::merge_batch(pairs4);
     for (size_t i = 0; i < pairs4.size(); i++) EXPECT(mb4[i] == I::merge(pairs4[i]), "merge_batch 4-3 item");
   }
+  // The five symbols the Rust patch binds (integration/rust/reference-patch/mi355x.rs), called the way the patch calls
+  // them: `&[Felt]` as one contiguous buffer of L u64 limbs per element cast to `*const u64` / `*mut u64`, lengths as
+  // size_t, at the patch's small-batch boundary MI355X_MIN_BATCH = 32 and one item either side of it.  Every item must
+  // equal the single-item trait function (what the CPU branch of the patch computes below the boundary).
+  {
+    using I = AnemoiBls12_381_2_1;
+    using J = AnemoiBn254_4_3;
+    static_assert(sizeof(I::F) == 6 * 8 && alignof(I::F) == 8 && sizeof(J::F) == 4 * 8, "Felt = L u64 limbs, as the patch asserts");
+    for (size_t n : {size_t(31), size_t(32), size_t(33)}) {
+      std::vector<I::F> st(2 * n), out(n);
+      for (size_t i = 0; i < st.size(); i++) st[i] = I::hash(std::vector<uint8_t>(1 + i % 7, uint8_t(i))).to_elements()[0];
+      EXPECT(anemoi_jive_compress_k_batch(ANEMOI_BLS12_381, 2, 2, (const uint64_t*)st.data(), (uint64_t*)out.data(), n, 0) == 0,
+             "anemoi_jive_compress_k_batch");
+      EXPECT(out[n - 1] == I::compress({st[2 * n - 2], st[2 * n - 1]})[0] && out[0] == I::compress({st[0], st[1]})[0], "compress_k_batch item");
+      std::vector<I::F> mo(n);
+      EXPECT(anemoi_merge_batch(ANEMOI_BLS12_381, (const uint64_t*)st.data(), (uint64_t*)mo.data(), n, 0) == 0, "anemoi_merge_batch");
+      EXPECT(mo == out, "merge = compress on Anemoi-2-1 (hasher.rs:86-92)");
+      std::vector<J::F> st4(4 * n), before;
+      for (size_t i = 0; i < st4.size(); i++) st4[i] = J::hash(std::vector<uint8_t>(2 + i % 5, uint8_t(3 * i))).to_elements()[0];
+      before = st4;
+      EXPECT(anemoi_permutation_batch(ANEMOI_BN_254, 4, (uint64_t*)st4.data(), n, 0) == 0, "anemoi_permutation_batch");
+      std::vector<J::F> one(before.begin() + 4 * (n - 1), before.end());
+      J::permutation_batch(one);
+      EXPECT(std::vector<J::F>(st4.begin() + 4 * (n - 1), st4.end()) == one, "permutation_batch item");
+      const size_t msg_len = 77;
+      std::vector<uint8_t> bytes(n * msg_len);
+      for (size_t i = 0; i < bytes.size(); i++) bytes[i] = uint8_t(i * 131 + 7);
+      std::vector<J::F> dig(n);
+      EXPECT(anemoi_hash_bytes_batch(ANEMOI_BN_254, 4, bytes.data(), msg_len, n, (uint64_t*)dig.data(), 0) == 0, "anemoi_hash_bytes_batch");
+      EXPECT(dig[n - 1] == J::hash(std::vector<uint8_t>(bytes.end() - msg_len, bytes.end())).to_elements()[0], "hash_batch item");
+      const size_t m = 5;
+      std::vector<J::F> hf(n);
+      EXPECT(anemoi_hash_field_batch(ANEMOI_BN_254, 4, (const uint64_t*)before.data(), m, (4 * n) / m, (uint64_t*)hf.data(), 0) == 0,
+             "anemoi_hash_field_batch");
+      EXPECT(hf[0] == J::hash_field(std::vector<J::F>(before.begin(), before.begin() + m)).to_elements()[0], "hash_field_batch item");
+    }
+  }
   // digest_elements / to_bytes (digest.rs:66-88): the zero digest serialises to zero bytes
   AnemoiBls12_381_2_1::D zero;
   for (auto b : zero.to_bytes()) EXPECT(b == 0, "to_bytes(zero)");

@@ -141,3 +141,23 @@ def test_sponge_segments_without_pinned_staging(A, oracle):
     with knobs(sponge_segment_bytes=n * unit * 2, host_staging="direct"):
         got = inst.hash_batch(msgs)
     assert (got == oracle.hash_bytes_batch(fid, 4, msgs, threads=4)).all()
+
+
+def test_unsorted_ragged_batch_is_bucketed_by_length_inside_the_library(A, oracle):
+    """A long-tailed, UNSORTED ragged batch (most messages short, a few long) is staged by descending block count and
+    the digests scattered back: every digest equals the oracle's hash of that message alone, in the caller's order --
+    in one chunk, through many small chunks, and sharded."""
+    rng = np.random.default_rng(4242)
+    for field, width in (("bn_254", 4), ("jubjub", 2), ("bls12_381", 2)):
+        fid, inst = FIELD_IDS.index(field), A.Anemoi(field, width)
+        n = 1500
+        lens = np.where(rng.integers(0, 12, size=n) == 0, rng.integers(900, 2500, size=n), rng.integers(0, 120, size=n))
+        msgs = [rng.integers(0, 256, size=int(v), dtype=np.uint8).tobytes() for v in lens]
+        got = inst.hash_ragged(msgs)
+        with knobs(chunk_target_bytes=8192, test_quantum=128):
+            many = inst.hash_ragged(msgs)
+            with knobs(virtual_devices=3):
+                shard = A.Anemoi(field, width, device=A.ALL_DEVICES).hash_ragged(msgs)
+        assert (got == many).all() and (got == shard).all(), (field, width)
+        for i in list(range(0, n, 11)) + [int(np.argmax(lens)), int(np.argmin(lens))]:
+            assert (got[i] == oracle.hash_bytes(fid, width, msgs[i])).all(), (field, width, i, int(lens[i]))

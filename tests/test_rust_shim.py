@@ -46,6 +46,83 @@ def test_header_parser_sees_every_symbol_the_ctypes_binding_has():
         assert len(params) == len(_lib._SIGS[name][0]), name
 
 
+# one table, three spellings of every parameter type that crosses the boundary: C header / ctypes binding / Rust -sys
+def type_table():
+    import ctypes as C
+    from anemoi_amd import _lib
+    P = C.POINTER
+    return {
+        "int": (C.c_int, "c_int"),
+        "unsigned": (C.c_uint, "c_uint"),
+        "unsigned int": (C.c_uint, "c_uint"),
+        "size_t": (C.c_size_t, "usize"),
+        "long long": (C.c_longlong, "c_longlong"),
+        "long long *": (P(C.c_longlong), "*mut c_longlong"),
+        "uint64_t *": (P(C.c_uint64), "*mut u64"),
+        "const uint64_t *": (P(C.c_uint64), "*const u64"),
+        "uint8_t *": (P(C.c_uint8), "*mut u8"),
+        "const uint8_t *": (P(C.c_uint8), "*const u8"),
+        "const char *": (C.c_char_p, "*const c_char"),
+        "void *": (C.c_void_p, "*mut c_void"),
+        "const void *": (C.c_void_p, "*const c_void"),
+        "const anemoi_generic_instance *": (P(_lib._GenericInstance), "*const AnemoiGenericInstance"),
+        "anemoi_generic_handle *": (C.c_void_p, "*mut AnemoiGenericHandle"),
+        "const anemoi_generic_handle *": (C.c_void_p, "*const AnemoiGenericHandle"),
+        "anemoi_generic_handle * *": (P(C.c_void_p), "*mut *mut AnemoiGenericHandle"),
+    }
+
+
+def rust_extern_types(text):
+    block = text[text.index('extern "C" {'):]
+    out = {}
+    for m in re.finditer(r"pub fn (anemoi_[a-z0-9_]+)\((.*?)\)\s*->\s*([^;]+);", block, flags=re.S):
+        args = [a.strip() for a in m.group(2).split(",") if a.strip()]
+        out[m.group(1)] = ([a.split(":", 1)[1].strip() for a in args], m.group(3).strip())
+    return out
+
+
+def test_parameter_types_agree_across_header_ctypes_and_rust():
+    """Not only names and arities: every parameter's TYPE -- pointer constness (`const uint64_t*` <-> `*const u64`),
+    `size_t` <-> `usize` <-> c_size_t, `unsigned` <-> `c_uint`, `uint8_t*` <-> `*mut u8`, the return types -- is the same
+    in the C header, in the ctypes binding the GPU tests call through, and in the generated `extern "C"` block."""
+    sys.path.insert(0, os.path.join(ROOT, "anemoi-rust_amd"))
+    from anemoi_amd import _lib
+    funcs, _ = gen_rust_sys.parse_header()
+    rust = rust_extern_types(open(LIB_RS).read())
+    import ctypes
+    TYPE_TABLE = type_table()
+    ret_table = {"int": (ctypes.c_int, "c_int"), "const char *": (ctypes.c_char_p, "*const c_char")}
+    for name, ret, params in funcs:
+        cty_args, cty_ret = _lib._SIGS[name]
+        r_args, r_ret = rust[name]
+        assert (cty_ret, r_ret) == ret_table[ret], (name, ret)
+        assert len(params) == len(cty_args) == len(r_args), name
+        for (ctype, pname), ca, ra in zip(params, cty_args, r_args):
+            want_ctypes, want_rust = TYPE_TABLE[ctype]
+            assert ca is want_ctypes, (name, pname, ctype, ca.__name__)
+            assert ra == want_rust, (name, pname, ctype, ra)
+            if "const" in ctype and "*" in ctype:
+                assert ra.startswith("*const"), (name, pname)     # inputs stay inputs on the Rust side
+            if ctype.endswith("*") and "const" not in ctype and "char" not in ctype:
+                assert ra.startswith("*mut"), (name, pname)
+
+
+def test_patch_passes_felt_slices_the_way_the_header_reads_them():
+    """The five symbols the reference patch calls take `&[Felt]` as `*const u64` / `*mut u64` (and bytes as `*const u8`),
+    lengths as usize, field / width / k / device as c_int: the casts written in mi355x.rs must produce exactly those."""
+    patch = open(PATCH).read()
+    rust = rust_extern_types(open(LIB_RS).read())
+    used = {"anemoi_jive_compress_k_batch": ["c_int", "c_int", "c_int", "*const u64", "*mut u64", "usize", "c_int"],
+            "anemoi_hash_bytes_batch": ["c_int", "c_int", "*const u8", "usize", "usize", "*mut u64", "c_int"],
+            "anemoi_hash_field_batch": ["c_int", "c_int", "*const u64", "usize", "usize", "*mut u64", "c_int"],
+            "anemoi_merge_batch": ["c_int", "*const u64", "*mut u64", "usize", "c_int"],
+            "anemoi_permutation_batch": ["c_int", "c_int", "*mut u64", "usize", "c_int"]}
+    for name, want in used.items():
+        assert rust[name][0] == want, (name, rust[name][0])
+    assert "as_ptr() as *const u64" in patch and "as_mut_ptr() as *mut u64" in patch
+    assert "as *const u8" in patch or "as_ptr()" in patch
+
+
 def test_patch_uses_existing_symbols_and_covers_all_instances(params):
     patch = open(PATCH).read()
     ext = rust_externs(open(LIB_RS).read())

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=os.path.join(ROOT, "anemoi-rust_amd", "lib", "libanemoi_mi355x.so"))
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-port column")
     args = ap.parse_args()
     lib = ctypes.CDLL(os.path.abspath(args.lib))
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
@@ -104,8 +105,37 @@ def main():
         "alu_frac": merges * buildinfo.mad_per_compression(4, 2) / (ms / 1e3) / PEAK_LANE_MAD,
         # merges per second against the flat Jubjub 2-1 Jive rate of this run: the tree's top levels are latency-bound
         "fraction_of_flat_rate": (merges / ms * 1e3) / out["extra_jubjub_2_1_x2^20"]["compress_per_s"]}
+    # ---- the CPU port beside every config (after and outside all GPU-timed regions) ----------
+    if not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import cpu_port
+        port = cpu_port.Port()
+        print("CPU baseline: " + port.describe())
+        # config 1 whole (1 024 Vesta compressions: BASELINE.json defines it as a CPU configuration)
+        one_us, rate = port.compress_us(6, 2, 4)
+        out["cfg1_vesta_2_1_x1024"]["cpu_port"] = {"us_per_compress_1_thread": one_us, "compress_per_s_all_threads": rate,
+                                                   "ms_for_1024_all_threads": 1024 / rate * 1e3, "threads": port.threads}
+        for key, fid, width, limbs in (("cfg2_bls12_381_2_1_x2^20", 0, 2, 6), ("cfg4_bls12_381_2_1_x2^21_per_gpu", 0, 2, 6),
+                                        ("extra_jubjub_2_1_x2^20", 4, 2, 4), ("extra_bn254_4_3_x2^20", 2, 4, 4),
+                                        ("extra_bls12_381_4_3_x2^19", 0, 4, 6)):
+            if key in out:
+                one_us, rate = port.compress_us(fid, width, limbs)
+                out[key]["cpu_port"] = {"us_per_compress_1_thread": one_us, "compress_per_s_all_threads": rate,
+                                        "threads": port.threads, "gpu_over_cpu_all_threads": out[key]["compress_per_s"] / rate}
+        # config 3 down-scaled: 2^6 messages' worth of time per thread, the full 10 240-byte message
+        k3 = [k for k in out if k.startswith("cfg3")][0]
+        one_us, rate = port.hash_us(2, 4, 10240, budget_s=3.0)
+        out[k3]["cpu_port"] = {"ms_per_message_1_thread": one_us / 1e3, "messages_per_s_all_threads": rate, "threads": port.threads,
+                               "gpu_over_cpu_all_threads": out[k3]["messages_per_s"] / rate}
+        # config 5 down-scaled: a depth-14 Jubjub tree on all threads (the GPU's depth-21 subtree has 128 x the merges)
+        k5 = [k for k in out if k.startswith("cfg5")][0]
+        ms14 = port.merkle_ms(4, 4, 14)
+        out[k5]["cpu_port"] = {"ms_depth14_all_threads": ms14, "merges_per_s_all_threads": ((1 << 14) - 1) / ms14 * 1e3,
+                               "threads": port.threads,
+                               "gpu_over_cpu_all_threads": out[k5]["merges_per_s"] / (((1 << 14) - 1) / ms14 * 1e3)}
     for k, v in out.items():
-        print("%-44s %s" % (k, json.dumps({a: (round(b, 3) if b < 1e4 else float("%.4g" % b)) for a, b in v.items()})))
+        print("%-44s %s" % (k, json.dumps({a: (b if isinstance(b, dict) else (round(b, 3) if b < 1e4 else float("%.4g" % b)))
+                                            for a, b in v.items()})))
     print(json.dumps(out))
 
 

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--fields", default=",".join(FIELDS))
     ap.add_argument("--big", type=int, default=18, help="log2 of the large compress batch")
     ap.add_argument("--msgs", type=int, default=14, help="log2 of the large hash batch")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-port column")
     ap.add_argument("--lib", default=os.path.join(ROOT, "anemoi-rust_amd", "lib", "libanemoi_mi355x.so"))
     args = ap.parse_args()
     lib = ctypes.CDLL(os.path.abspath(args.lib))
@@ -86,11 +87,26 @@ def main():
             single = timed(lambda: run(1), reps=2)
             big = timed(lambda: run(nm), reps=2) / nm
             rows.append((name, label, single, big, README_US.get((name, label))))
-    print("%-16s %-16s %14s %18s %16s" % ("field", "workload", "1 call [us]", "per item, batched", "reference CPU"))
+    # the CPU port on THIS host, one call on one thread (what criterion measures), after all GPU timing
+    cpu = {}
+    if not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import cpu_port
+        port = cpu_port.Port()
+        print("CPU baseline: " + port.describe())
+        for name in args.fields.split(","):
+            fid, L = FIELDS.index(name), LIMBS[FIELDS.index(name)]
+            for label, width, k in (("compress/2-1", 2, 2), ("compress/4-3", 4, 2), ("compress_k4/4-3", 4, 4)):
+                cpu[(name, label)] = port.compress_us(fid, width, L, k=k, budget_s=0.6)[0]
+            for label, width in (("hash10KB/2-1", 2), ("hash10KB/4-3", 4)):
+                cpu[(name, label)] = port.hash_us(fid, width, 10240, budget_s=0.3)[0]
+    print("%-16s %-16s %14s %18s %18s %16s" % ("field", "workload", "1 call [us]", "per item, batched", "CPU port, 1 call", "reference README"))
     for name, label, single, big, ref in rows:
-        print("%-16s %-16s %14.1f %15.3f us %13s" % (name, label, single, big, ("%.2f us" % ref) if ref else "-"))
+        c = cpu.get((name, label))
+        print("%-16s %-16s %14.1f %15.3f us %15s %16s" % (name, label, single, big, ("%.2f us" % c) if c else "-",
+                                                           ("%.2f us" % ref) if ref else "-"))
     print(json.dumps([{"field": r[0], "workload": r[1], "single_call_us": r[2], "batched_us_per_item": r[3],
-                       "reference_cpu_us": r[4]} for r in rows]))
+                       "cpu_port_us_one_thread": cpu.get((r[0], r[1])), "reference_readme_cpu_us": r[4]} for r in rows]))
 
 
 if __name__ == "__main__":
