@@ -78,26 +78,43 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typ
       tab[i * kBlock + lane] = pw;
     }
     uint32_t acc = tab[pc.first5 * kBlock + lane], tmp = acc;
-    // A lone wavefront pays every instruction between two products, so the step loop is kept lean: the NEXT step's
-    // schedule word is fetched (scalar load) before this step's products, the table operand is read from LDS before
-    // the squarings (clamped instead of branched around for the "no multiplication" step), and the tmp-register
+    // A lone wavefront pays every instruction -- and every exposed latency -- between two products, so the step loop
+    // is software-pipelined: the schedule word of step s + 2 (scalar load) and the table operand of step s + 1 (LDS,
+    // its address from the word fetched a step earlier) are requested BEFORE step s's products and waited for after
+    // them; the operand is clamped instead of branched around for the "no multiplication" step; the tmp-register
     // operations of the leading-run doubling exist only for the fields whose schedule uses them (Pallas / Vesta).
-    uint32_t word = uniform_word(pc.sched5, 0);
+    // (The words one and two past the end of the schedule are inside the constants blob.)
+    // (volatile: hipcc otherwise re-reads the operand inside the step instead of carrying it across the back-edge, and
+    // then waits for it in front of the products)
+    typedef const volatile uint32_t __attribute__((address_space(3))) * LdsWords;
+    const LdsWords vtab = (LdsWords)(uintptr_t)tab;   // (tab is __shared__: the low 32 bits of the flat address are the LDS offset)
+    auto operand_of = [&](uint32_t w) {
+      const uint32_t i = w >> 8;
+      return vtab[(i < uint32_t(E) ? i : 0u) * kBlock + lane];
+    };
+    uint32_t word = uniform_word(pc.sched5, 0), next = uniform_word(pc.sched5, 1);
+    uint32_t opnd = operand_of(word);
 #pragma nounroll
     for (int s = 0; s < pc.steps5; s++) {
-      const uint32_t next = uniform_word(pc.sched5, s + 1);   // (one word past the end on the last step: inside the blob)
+      const uint32_t after = uniform_word(pc.sched5, s + 2);
+      const uint32_t opnd_next = operand_of(next);
       const uint32_t nsq = word & 0xff, idx = word >> 8;
-      word = next;
+      uint32_t b = opnd;
+      word = next, next = after, opnd = opnd_next;
       if constexpr (F::kChainTmp) {
         if (idx == 253) {  // leading-run doubling, see sliding_window() in tools/gen_params.py
           tmp = acc;
           continue;
         }
+        b = idx == 254 ? tmp : b;
       }
-      const uint32_t opnd = tab[(idx < uint32_t(E) ? idx : 0u) * kBlock + lane];
-      if (nsq) acc = C::sqr_n(acc, nsq, k);
-      if (F::kChainTmp && idx == 254) acc = C::mul(acc, tmp, k);
-      else if (idx != 255) acc = C::mul(acc, opnd, k);
+      if (idx == 255) {            // the trailing squarings of the exponent
+        if (nsq) acc = C::sqr_n(acc, nsq, k);
+      } else if (nsq) {
+        acc = C::sqr_mul(acc, nsq, b, k);   // one statement: the operand's lane shifts ride in the last squaring
+      } else {
+        acc = C::mul(acc, b, k);
+      }
     }
     t = acc;
   }

@@ -138,6 +138,9 @@ struct Coop29 {
   __device__ static __forceinline__ uint32_t mul(uint32_t a, uint32_t b, const K& k) { return mul(a, b, k.pl); }
   __device__ static __forceinline__ uint32_t sub(uint32_t a, uint32_t b, const K& k) { return sub(a, b, k.kpl); }
   __device__ static __forceinline__ uint32_t to_mont(uint32_t x, const K& k) { return mul(x, k.rr, k.pl); }
+  __device__ static __forceinline__ uint32_t sqr_mul(uint32_t a, uint32_t n, uint32_t b, const K& k) {   // a^(2^n) b
+    return mul(sqr_n(a, n, k), b, k.pl);
+  }
   __device__ static __forceinline__ uint32_t sqr_n(uint32_t a, uint32_t n, const K& k) {   // a^(2^n)
 #pragma nounroll
     for (uint32_t i = 0; i < n; i++) a = mul(a, a, k.pl);

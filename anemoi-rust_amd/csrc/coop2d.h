@@ -21,7 +21,7 @@
 //   RN2      HI is carried per row, summed over the rows, carried again: limbs < 2^28 + 2^5, value < 2^33 p
 //
 // ~75 (11 limbs) / ~95 (15 limbs) issue slots per product against ~108 / ~158 for the scan.  The price: results are
-// never tight, so (i) every difference is settled at once (sub() multiplies by R' mod p), (ii) the one product whose
+// never tight, so (i) values are settled (multiplied by R' mod p) once per round, after the linear layer, (ii) the one product whose
 // result has to be < 2p -- the conversion to the ABI form -- runs a digit-serial scan in the same layout (mul_exact),
 // once per output element.
 //
@@ -32,7 +32,14 @@
 #include <type_traits>
 
 #include "field_consts_gen.h"
+#if defined(ANEMOI_COOP2D_NOVDST) && ANEMOI_COOP2D_NOVDST
+#include "coop2d_asm_gen_novdst.h"   // A/B: the same statements without hazard padding of DPP destinations (not shipped)
+#else
 #include "coop2d_asm_gen.h"   // tools/gen_coop2d_asm.py: the product below, hand-scheduled
+#endif
+#ifndef ANEMOI_COOP2D_FUSE
+#define ANEMOI_COOP2D_FUSE 1     // 0: an exponentiation step = a squaring-run statement + a multiplication statement (A/B)
+#endif
 #ifndef ANEMOI_ASM_MUL
 #define ANEMOI_ASM_MUL 1
 #endif
@@ -166,6 +173,21 @@ struct Coop2d {
     for (uint32_t i = 0; i < n; i++) a = mul_cxx(a, a, k);
     return a;
   }
+  // x^(2^n) * b, n >= 1: one step of the sliding-window exponentiation (the assembly issues b's lane shifts in the
+  // hazard gaps of the last squaring)
+  // Measured in one process (profiles/r04/ab_coop2d_fused_steps.txt): the fused statement is 3.6 % faster on 11 limbs
+  // (Jubjub 1.118 -> 1.078 ms) and 9 % SLOWER on 15 (BLS12-381 1.838 -> 2.010 ms: sixteen more live registers and
+  // eighteen prefetched shifts for a step that is mostly squarings), so the 15-limb fields keep two statements per step.
+  static constexpr bool kFuseSteps = ANEMOI_COOP2D_FUSE && NL <= 13;
+  __device__ static __forceinline__ uint32_t sqr_mul(uint32_t a, uint32_t n, uint32_t b, const K& k) {
+#if ANEMOI_ASM_MUL
+    if constexpr (!kFuseSteps) return mul(sqr_n(a, n, k), b, k);
+    else if constexpr (NL > 13) return AsmCoop2d<NL, W>::sqr_mul(a, b, k.ct, k.mtop, k.only15, n);
+    else return AsmCoop2d<NL, W>::sqr_mul(a, b, k.ct, n);
+#endif
+    for (uint32_t i = 0; i < n; i++) a = mul_cxx(a, a, k);
+    return mul_cxx(a, b, k);
+  }
   // the readable form of the same product (ANEMOI_ASM_MUL=0 builds run it)
   __device__ static __forceinline__ uint32_t mul_cxx(uint32_t a, uint32_t b, const K& k) {
     const uint32_t aD = odd_rows_from_next(a), bS = odd_rows_from_prev(b);
@@ -251,9 +273,12 @@ struct Coop2d {
   __device__ static __forceinline__ uint32_t add(uint32_t a, uint32_t b) { return carry32(a + b); }
   __device__ static __forceinline__ uint32_t settle(uint32_t x, const K& k) { return mul(x, k.one, k); }
 
-  // a - b + 2^s p, settled at once: b < 2^s p (what the S-box subtracts: g * product or a product, field_consts_gen.h)
+  // a - b + 2^s p for b < 2^s p (what the S-box subtracts: g * (a product of settled values) or a product; the pad is
+  // field_consts_gen.h's KP).  NOT settled: R'/p >= 2^39 leaves room for the few pads a round accumulates before
+  // coop_permutation settles x and y after the linear layer -- tests/test_coop2d_model.py walks the bounds of a round
+  // for every field (every subtrahend <= the pad, every value < R', every product's column sums inside 64 bits).
   __device__ static __forceinline__ uint32_t sub(uint32_t a, uint32_t b, const K& k) {
-    return settle(carry32(a + k.kpl - norm_exact(b)), k);
+    return carry32(a + k.kpl - norm_exact(b));
   }
 
   // g * x (mul_by_generator, src/traits.rs:78-91)

@@ -56,6 +56,59 @@ def test_model_against_big_integers(moduli):
                 assert L.value(r) < (1 << 33) * L.p, f
 
 
+def test_bounds_of_a_round(moduli, params):
+    """The fold arithmetic never reduces below 2p: it relies on R'/p >= 2^39 and on ONE settle of x and y per round
+    (coop_permutation, after the linear layer).  Walk the bounds of a round (in units of p, exact fractions) the way
+    coop_permutation / coop_flystel compute it and check: every subtrahend is <= the pad of `sub`, every value stays
+    below R', the Jive output's digit-serial product ends below 2p -- and run the model's product with every limb at its
+    maximum at the largest bounds a product meets (64-bit column sums, 32-bit carries)."""
+    from fractions import Fraction as Fr
+    import math
+    for f, L in layouts(moduli).items():
+        g = params[f]["beta"]
+        H = Fr(L.R, L.p)
+        fold = L.NL * (L.M + 33) + 2          # sum_k t_k C_k < NL (2^W + 32) p, plus the carries
+        K = Fr(1 << math.ceil(math.log2(g) + 32.5))
+        cap = H                                # values must stay below R' = H p
+        worst_in = [Fr(0)]
+
+        def mul(a, b):
+            worst_in[0] = max(worst_in[0], a, b)
+            return a * b / H + fold
+
+        S = mul(cap / 2, Fr(1))                # settle(v) = v * (R' mod p): whatever v was (< R'), the result is ~fold
+        x = y = S
+        for _ in range(3):                     # the bounds reach their fixed point at once; three rounds to be sure
+            x, y = x + 1, y + 1                # ark_layer: canonical constants
+            y = y + x                          # mds_layer, arm 1 (src/traits.rs:136-142)
+            x = x + y
+            assert x < cap and y < cap, (f, float(x), float(cap))
+            x, y = mul(x, Fr(1)), mul(y, Fr(1))          # settle
+            t = mul(y, y)
+            gt = g * t
+            assert gt <= K, (f, "first subtrahend", float(gt), float(K))
+            x = x + K                                    # x - g y^2 + pad
+            pw = mul(x, x)
+            for _ in range(40):                          # table powers and the exponentiation: products of products
+                pw = mul(max(pw, x), max(pw, x))
+            e = pw
+            assert e <= K, (f, "second subtrahend", float(e), float(K))
+            y = y + K                                    # y - x^(1/alpha) + pad
+            t = mul(y, y)
+            x = x + g * t + 1
+            assert x < cap and y < cap
+        jive = 2 * (x + y)                               # state[0] + state[1] + elems (all four below max(x, y))
+        assert jive / H + 1 < 2, (f, "mul_exact for to_abi must end below 2p")
+        bits = math.ceil(math.log2(worst_in[0]))
+        assert (1 << bits) * L.p < L.R
+        rng = random.Random(5)
+        ops = operands(L, rng, bound_bits=bits)
+        for a in ops[:3]:
+            for b in ops[:3]:
+                r = M.mul(L, a, b)                       # raises Overflow if a column sum or a carry does not fit
+                assert (L.value(r) * L.R - L.value(a) * L.value(b)) % L.p == 0
+
+
 def test_model_notices_an_overflow(moduli):
     """sanity of the checker: limbs twice as large as the layout allows must trip it"""
     L = layouts(moduli)["bls12_381"]
@@ -151,9 +204,11 @@ def run_asm(lines, opnd):
             opnd[args[0]] = (opnd[args[1]] - int(args[2], 0)) & M32
         elif op == "s_cmp_lg_u32":
             scc = int(opnd[args[0]] != int(args[1], 0))
+        elif op == "s_cmp_eq_u32":
+            scc = int(opnd[args[0]] == int(args[1], 0))
         elif op == "s_cbranch_scc1":
             if scc:
-                pc = labels[args[0][:-1]]       # "1b" -> label "1"
+                pc = labels[args[0][:-1]]       # "1b" / "2f" -> label "1" / "2"
         elif op == "v_mov_b32":
             put(args[0], get(args[1]))
         elif op == "v_mov_b32_dpp":
@@ -214,39 +269,46 @@ def wave(rows):
 def test_generated_assembly_on_the_lane_interpreter(moduli, field):
     L = layouts(moduli)[field]
     rng = random.Random(7)
-    names_mul = G.operand_names(L.NL, False, False)
-    names_sqr = G.operand_names(L.NL, True, True)
-    mul_lines = G.gen_product(L.NL, L.W, False, False)[0]
-    sqr_lines = G.gen_product(L.NL, L.W, True, True)[0]
+    names = {k: G.operand_names(L.NL, k) for k in G.KINDS}
+    lines = {k: G.gen_product(L.NL, L.W, k)[0] for k in G.KINDS}
     ct = [[(L.C[2 * q + ((lane >> 4) & 1)] >> (L.W * (lane & 15))) & L.M if (2 * q + ((lane >> 4) & 1) < L.NL and (lane & 15) < L.NL) else 0
            for lane in range(64)] for q in range(L.Q)]
     extra = {}
     if L.NL > 13:
         extra = {"MTOP": [0xffffffff if (lane & 15) == 15 else L.M for lane in range(64)],
                  "ONLY15": [0xffffffff if (lane & 15) == 15 else 0 for lane in range(64)]}
+
+    def run(kind, a2, b2=None, n=None):
+        nm = names[kind]
+        opnd = {nm["A"]: wave(a2)}
+        if b2 is not None:
+            opnd[nm["B"]] = wave(b2)
+        if n is not None:
+            opnd[nm["CNT"]] = n
+        opnd.update({nm["CT"][q]: ct[q] for q in range(L.Q)})
+        opnd.update({nm[k]: val for k, val in extra.items()})
+        return run_asm(lines[kind], opnd)
+
+    def both_rows(r, e, want, what):
+        for row in (2 * e, 2 * e + 1):
+            assert r[row * 16:(row + 1) * 16] == want, (field, what, e, row)
+
     ops = operands(L, rng)
     for trial in range(12):
         a2 = [ops[(trial * 3 + e) % len(ops)] for e in range(2)]          # the two elements of the wavefront differ
         b2 = [ops[(trial * 5 + 2 * e + 1) % len(ops)] for e in range(2)]
-        opnd = {names_mul["A"]: wave(a2), names_mul["B"]: wave(b2)}
-        opnd.update({names_mul["CT"][q]: ct[q] for q in range(L.Q)})
-        opnd.update({names_mul[k]: val for k, val in extra.items()})
-        r = run_asm(mul_lines, opnd)
+        r = run("mul", a2, b2)
         for e in range(2):
-            want = M.mul(L, a2[e], b2[e])          # the specification, limb for limb
-            for row in (2 * e, 2 * e + 1):
-                assert r[row * 16:(row + 1) * 16] == want, (field, trial, e, row)
-        # a run of n squarings = n products of the model
-        for n in (1, 3):
-            opnd = {names_sqr["A"]: wave(a2), names_sqr["CNT"]: n}
-            opnd.update({names_sqr["CT"][q]: ct[q] for q in range(L.Q)})
-            opnd.update({names_sqr[k]: val for k, val in extra.items()})
-            r = run_asm(sqr_lines, opnd)
+            both_rows(r, e, M.mul(L, a2[e], b2[e]), ("mul", trial))      # the specification, limb for limb
+        for n in (1, 2, 4):      # a run of n squarings = n products of the model; then the multiplication
+            r = run("sqr_run", a2, n=n)
+            r2 = run("sqr_mul", a2, b2, n=n)
             for e in range(2):
                 want = a2[e]
                 for _ in range(n):
                     want = M.mul(L, want, want)
-                assert r[(2 * e) * 16:(2 * e + 1) * 16] == want and r[(2 * e + 1) * 16:(2 * e + 2) * 16] == want, (field, trial, n, e)
+                both_rows(r, e, want, ("sqr_run", trial, n))
+                both_rows(r2, e, M.mul(L, want, b2[e]), ("sqr_mul", trial, n))
 
 
 def test_hazard_distances_of_the_emitted_text():
@@ -254,12 +316,15 @@ def test_hazard_distances_of_the_emitted_text():
     destination of a *_dpp instruction) or by v_permlane16_swap within the next two issue slots -- also across the
     back-edge of the squaring loop (checked by unrolling the body twice)."""
     for nl, W in G.LAYOUTS:
-        for square, loop in ((False, False), (True, True)):
-            lines = G.gen_product(nl, W, square, loop)[0]
-            if loop:
+        for kind in G.KINDS:
+            lines = G.gen_product(nl, W, kind)[0]
+            # unroll every loop body twice so that the back-edges are checked as straight-line code (a forward branch
+            # is checked as fall-through: its target sees at least the registers written before the branch)
+            if "1:" in lines:
                 i0 = lines.index("1:")
-                i1 = next(i for i, l in enumerate(lines) if l.startswith("s_cbranch_scc1"))
+                i1 = lines.index("s_cbranch_scc1 1b")
                 lines = lines[:i0] + lines[i0 + 1:i1 + 1] + lines[i0 + 1:]
+            lines = [l for l in lines if not l.endswith(":")]
             slot, wrote = 0, {}
             for ln in lines:
                 op, _, rest = ln.partition(" ")
@@ -280,7 +345,7 @@ def test_hazard_distances_of_the_emitted_text():
                     sensitive = flat[0] + flat[1]
                 for r in sensitive:
                     if r in wrote:
-                        assert slot - wrote[r] - 1 >= 2, (nl, square, ln, r)
+                        assert slot - wrote[r] - 1 >= 2, (nl, kind, ln, r)
                 if op.startswith("v_"):
                     written = flat[0] + (flat[1] if op.startswith("v_permlane16_swap") else [])
                     for r in written:
