@@ -17,12 +17,17 @@
 
 namespace anemoi {
 
-// Lanes per item -> the cooperative arithmetic: 64 / 16 = the digit-serial scan of coop29.h (one item per wavefront /
-// one per DPP row), 32 = the two-row fold product of coop2d.h (two items per wavefront, the lowest latency)
-template <class F, int LPI>
+// Lanes per item -> the cooperative arithmetic:
+//   16   the digit-serial scan of coop29.h, one item per DPP row (four per wavefront)
+//   32   the two-row fold product of coop2d.h (two items per wavefront)
+//   64   one item per wavefront (A/B and parity only): the FOUR-row fold product where it exists (11-limb fields), else
+//        the one-element scan of coop29.h (rounds 1-2's kernel)
+template <class F, int LPI, bool FOUR_ROWS = (F::Fold::Q4 > 0)>
 struct CoopArith { using type = Coop29<F, LPI>; };
+template <class F, bool FR>
+struct CoopArith<F, 32, FR> { using type = Coop2d<F, 2>; };
 template <class F>
-struct CoopArith<F, 32> { using type = Coop2d<F>; };
+struct CoopArith<F, 64, true> { using type = Coop2d<F, 4>; };
 
 // ---- wave-cooperative Jive 2-to-1 compression (coop29.h, coop2d.h) ------------------------------------
 // Latency path: small batches (the top levels of a Merkle tree, a single Jive::compress / Sponge::merge call).
@@ -40,6 +45,12 @@ struct CoopArith<F, 32> { using type = Coop2d<F>; };
 // MI355X's 1 024 SIMDs, and the automatic cut-offs are stated that way (`simds` = 4 x the device's CU count, so a
 // partitioned or smaller device scales them).  Each is an option (options.h: read from the environment ONCE, changed
 // through anemoi_set_option; the parity tests force each kernel for every size that way).
+// One item per wavefront (k_jive2_coop<F, 64>): NEVER by default -- A/B and parity only.  On the 11-limb fields this is
+// the FOUR-row fold product (an element on all four rows: half the multiply-adds per wavefront, 67 instructions per
+// squaring instead of 73), which measures SLOWER than the two-row form (Jubjub 1.145 vs 1.073 ms per compression,
+// profiles/r04/coop_kernel_sweep.txt): its two extra swap levels and three-row form builds leave 18 hazard slots per
+// product that nothing can fill (85 issue slots against 79), and a lone wavefront pays for every slot.  On the 15-limb
+// fields it is rounds 1-2's one-element scan kernel.
 inline size_t coop_max_items() { return size_t(opt::get_or(opt::kCoopMax, 0)); }
 // Anemoi-2-1 batches up to this size take the two-row fold kernels (coop2d.h, two items per wavefront): one
 // wavefront per SIMD -- beyond that the second wavefront of a SIMD costs more than the scan kernel's extra instructions
@@ -129,8 +140,8 @@ struct CoopArk {
   __device__ static __forceinline__ const uint32_t* c(const PermConsts& pc) { return pc.coop_c; }
   __device__ static __forceinline__ const uint32_t* d(const PermConsts& pc) { return pc.coop_d; }
 };
-template <class F>
-struct CoopArk<Coop2d<F>> {
+template <class F, int ROWS>
+struct CoopArk<Coop2d<F, ROWS>> {
   __device__ static __forceinline__ const uint32_t* c(const PermConsts& pc) { return pc.fold_c; }
   __device__ static __forceinline__ const uint32_t* d(const PermConsts& pc) { return pc.fold_d; }
 };

@@ -768,7 +768,7 @@ struct Launch {
 
   static hipError_t jive(int width, int k, const void* in, void* out, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (width == 2 && n <= coop_max_items()) {  // latency path: one item per wavefront
+    if (width == 2 && n <= coop_max_items()) {  // A/B and parity only: one item per wavefront (four-row fold on 11 limbs, else the scan)
       const unsigned g = n < 65536 ? unsigned(n) : 65536u;  // the kernel strides over items
       k_jive2_coop<FIELD, 64><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
@@ -804,7 +804,7 @@ struct Launch {
   static hipError_t sponge_seg(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
                                SpongeSeg seg, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (seg.first && seg.last && width == 2 && n <= coop2d_max_items(pc.simds)) {  // lowest latency: two messages per wavefront
+    if (seg.first && seg.last && width == 2 && n <= coop2d_max_items(pc.simds)) {  // two messages per wavefront
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       if (bytes) k_sponge_coop<FIELD, 2, true, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);

@@ -46,14 +46,20 @@
 
 namespace anemoi {
 
-template <class F>
+// ROWS = 2: an element on a row pair, two per wavefront.  ROWS = 4 (11-limb fields): an element on all four rows, ONE
+// per wavefront -- row r multiplies by the limbs a_i, i = r (mod 4), so a phase takes ceil(NL / 4) steps: half the
+// multiply-adds, broadcasts and shifts per wavefront for a second swap level (v_permlane32_swap) in the sums over the
+// rows.  Built, bit-exact, and MEASURED SLOWER than two rows (18 unfillable hazard slots per product against 6: 85 issue
+// slots against 79; Jubjub 1.145 vs 1.073 ms): kept selectable (option coop_max) as the recorded negative, not routed to.
+template <class F, int ROWS = 2>
 struct Coop2d {
   using L = typename F::Fold;
-  static constexpr int W = L::W, NL = L::NL, Q = L::Q, OFF = L::OFF;
+  static_assert(ROWS == 2 || (ROWS == 4 && L::Q4 > 0), "four rows: 11-limb fields only (the S form shifts b up by three lanes)");
+  static constexpr int W = L::W, NL = L::NL, Q = ROWS == 2 ? L::Q : L::Q4, OFF = L::OFF;
   static constexpr int NABI = F::N;
-  static constexpr int kLanesPerItem = 32;   // two 16-lane rows
+  static constexpr int kLanesPerItem = 16 * ROWS;
   static constexpr uint32_t MASK = (1u << W) - 1;
-  static_assert((W == 27 || W == 28) && NL <= 15 && OFF == 16 - NL && Q == (NL + 1) / 2, "layout of tools/coop2d_model.py");
+  static_assert((W == 27 || W == 28) && NL <= 15 && OFF == 16 - NL && Q == (NL + ROWS - 1) / ROWS, "layout of tools/coop2d_model.py");
 
   // ---- DPP / cross-row primitives ---------------------------------------------------------------------------------
   template <int CTRL>
@@ -103,7 +109,8 @@ struct Coop2d {
   __device__ static __forceinline__ uint32_t limb() { return threadIdx.x & 15u; }
   __device__ static __forceinline__ uint32_t row0() { return threadIdx.x & ~15u; }   // first lane of this lane's row
   __device__ static __forceinline__ bool odd_row() { return (threadIdx.x >> 4) & 1u; }
-  __device__ static __forceinline__ bool writer() { return !odd_row(); }             // the row that stores results
+  __device__ static __forceinline__ uint32_t row_in_item() { return (threadIdx.x >> 4) & uint32_t(ROWS - 1); }
+  __device__ static __forceinline__ bool writer() { return row_in_item() == 0; }     // the row that stores results
   __device__ static __forceinline__ uint32_t keep(uint32_t v) { return limb() < NL ? v : 0u; }
   __device__ static __forceinline__ uint32_t konst(const uint32_t* __restrict__ k) {
     return limb() < NL ? k[limb()] : 0u;
@@ -117,9 +124,9 @@ struct Coop2d {
   __device__ static __forceinline__ K load_consts() {
     K k{konst(L::P), konst(L::KP), konst(L::Delta), konst(L::One), konst(L::GMont), konst(L::In), konst(L::Out),
         konst(L::RR), {}};
-    const uint32_t h = odd_row() ? 1u : 0u;
+    const uint32_t h = row_in_item();
 #pragma unroll
-    for (int q = 0; q < Q; q++) k.ct[q] = L::FoldT[(q * 2 + h) * 16 + limb()];
+    for (int q = 0; q < Q; q++) k.ct[q] = ROWS == 2 ? L::FoldT[(q * 2 + h) * 16 + limb()] : L::FoldT4[(q * 4 + h) * 16 + limb()];
     k.mtop = limb() == 15 ? 0xffffffffu : MASK;
     k.only15 = limb() == 15 ? 0xffffffffu : 0u;
     return k;
@@ -159,16 +166,16 @@ struct Coop2d {
   // tools/coop2d_model.py::mul is this function lane for lane.
   __device__ static __forceinline__ uint32_t mul(uint32_t a, uint32_t b, const K& k) {
 #if ANEMOI_ASM_MUL
-    if constexpr (NL > 13) return AsmCoop2d<NL, W>::mul(a, b, k.ct, k.mtop, k.only15);
-    else return AsmCoop2d<NL, W>::mul(a, b, k.ct);
+    if constexpr (NL > 13) return AsmCoop2d<NL, W, ROWS>::mul(a, b, k.ct, k.mtop, k.only15);
+    else return AsmCoop2d<NL, W, ROWS>::mul(a, b, k.ct);
 #endif
     return mul_cxx(a, b, k);
   }
   // x^(2^n), n >= 1: a run of squarings (the assembly keeps the loop inside one statement)
   __device__ static __forceinline__ uint32_t sqr_n(uint32_t a, uint32_t n, const K& k) {
 #if ANEMOI_ASM_MUL
-    if constexpr (NL > 13) return AsmCoop2d<NL, W>::sqr_run(a, k.ct, k.mtop, k.only15, n);
-    else return AsmCoop2d<NL, W>::sqr_run(a, k.ct, n);
+    if constexpr (NL > 13) return AsmCoop2d<NL, W, ROWS>::sqr_run(a, k.ct, k.mtop, k.only15, n);
+    else return AsmCoop2d<NL, W, ROWS>::sqr_run(a, k.ct, n);
 #endif
     for (uint32_t i = 0; i < n; i++) a = mul_cxx(a, a, k);
     return a;
@@ -178,18 +185,19 @@ struct Coop2d {
   // Measured in one process (profiles/r04/ab_coop2d_fused_steps.txt): the fused statement is 3.6 % faster on 11 limbs
   // (Jubjub 1.118 -> 1.078 ms) and 9 % SLOWER on 15 (BLS12-381 1.838 -> 2.010 ms: sixteen more live registers and
   // eighteen prefetched shifts for a step that is mostly squarings), so the 15-limb fields keep two statements per step.
-  static constexpr bool kFuseSteps = ANEMOI_COOP2D_FUSE && NL <= 13;
+  static constexpr bool kFuseSteps = ANEMOI_COOP2D_FUSE && NL <= 13;   // (both row counts of the 11-limb fields)
   __device__ static __forceinline__ uint32_t sqr_mul(uint32_t a, uint32_t n, uint32_t b, const K& k) {
 #if ANEMOI_ASM_MUL
     if constexpr (!kFuseSteps) return mul(sqr_n(a, n, k), b, k);
-    else if constexpr (NL > 13) return AsmCoop2d<NL, W>::sqr_mul(a, b, k.ct, k.mtop, k.only15, n);
-    else return AsmCoop2d<NL, W>::sqr_mul(a, b, k.ct, n);
+    else if constexpr (NL > 13) return AsmCoop2d<NL, W, ROWS>::sqr_mul(a, b, k.ct, k.mtop, k.only15, n);
+    else return AsmCoop2d<NL, W, ROWS>::sqr_mul(a, b, k.ct, n);
 #endif
     for (uint32_t i = 0; i < n; i++) a = mul_cxx(a, a, k);
     return mul_cxx(a, b, k);
   }
   // the readable form of the same product (ANEMOI_ASM_MUL=0 builds run it)
   __device__ static __forceinline__ uint32_t mul_cxx(uint32_t a, uint32_t b, const K& k) {
+    if constexpr (ROWS == 4) return mul_cxx4(a, b, k);
     const uint32_t aD = odd_rows_from_next(a), bS = odd_rows_from_prev(b);
     uint64_t LO = 0, HI = 0;
     static_for<0>([&](auto I) {   // P1
@@ -241,6 +249,62 @@ struct Coop2d {
       // (lanes >= NL stay zero by themselves: no product or table entry reaches them and the value is far below R')
       return (y & MASK) + from_prev(y >> W);
     }
+  }
+
+  // ---- four rows per element (tools/coop2d_model.py::mul4) -------------------------------------------------------------
+  __device__ static __forceinline__ void swap32(uint32_t& a, uint32_t& b) {   // rows 2, 3 of a <-> rows 0, 1 of b
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+  }
+  template <int SHL>   // rows 1, 2, 3 shifted by 1, 2, 3 lanes (down: D form of a multiplier; up: S form of a multiplicand)
+  __device__ static __forceinline__ uint32_t skew(uint32_t v) {
+    constexpr int base = SHL ? 0x100 : 0x110;
+    uint32_t r = v;
+    r = (uint32_t)__builtin_amdgcn_update_dpp((int)r, (int)v, base + 1, 0x2, 0xf, true);
+    r = (uint32_t)__builtin_amdgcn_update_dpp((int)r, (int)v, base + 2, 0x4, 0xf, true);
+    r = (uint32_t)__builtin_amdgcn_update_dpp((int)r, (int)v, base + 3, 0x8, 0xf, true);
+    return r;
+  }
+  __device__ static __forceinline__ uint64_t sum4(uint64_t v) {   // the sum over the four rows, in every row
+    uint32_t l0 = (uint32_t)v, h0 = (uint32_t)(v >> 32), l1 = l0, h1 = h0;
+    swap16(l0, l1);
+    swap16(h0, h1);
+    v = (((uint64_t)h0 << 32) | l0) + (((uint64_t)h1 << 32) | l1);
+    l0 = (uint32_t)v, h0 = (uint32_t)(v >> 32), l1 = l0, h1 = h0;
+    swap32(l0, l1);
+    swap32(h0, h1);
+    return (((uint64_t)h0 << 32) | l0) + (((uint64_t)h1 << 32) | l1);
+  }
+  __device__ static __forceinline__ uint32_t mul_cxx4(uint32_t a, uint32_t b, const K& k) {
+    static_assert(ROWS != 4 || (NL <= 13 && W <= 27), "the four-row form is built for the 11-limb, 27-bit layout");
+    const uint32_t aD = skew<1>(a), bS = skew<0>(b);
+    uint64_t LO = 0, HI = 0;
+    static_for<0>([&](auto I) {
+      constexpr int q = decltype(I)::value;
+      const uint32_t aq = bcast<4 * q>(aD);
+      LO += (uint64_t)aq * shr<OFF + 4 * q>(bS);
+      HI += (uint64_t)aq * shl<NL - 4 * q>(bS);
+    });
+    // RN1: low and high parts summed over the four rows (swap16, swap32), then distributed (swap16)
+    uint32_t lo = (uint32_t)LO & MASK, hi = (uint32_t)(LO >> W);
+    swap16(lo, hi);
+    uint32_t s = lo + hi, x = s;          // rows: lo0+lo1, hi0+hi1, lo2+lo3, hi2+hi3
+    swap32(s, x);
+    uint32_t u = s + x, y = u;            // rows: low parts, high parts, low parts, high parts
+    swap16(u, y);                         // u = low parts, y = high parts, in all four rows
+    const uint32_t v = u + from_prev(y), vh = v >> W;
+    const uint32_t cc = y + vh;           // lane 15: everything column NL-1 hands on; lanes 0..2 are zero (OFF >= 3)
+    const uint32_t t = (v & MASK) + from_prev(vh);
+    HI += (uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)cc, 0x121, 0x1, 0x1, false);   // row 0, lane 0 <- lane 15
+    const uint32_t tD = skew<1>(t);
+    static_for<0>([&](auto I) {           // P2: fold
+      constexpr int q = decltype(I)::value;
+      HI += (uint64_t)bcast<OFF + 4 * q>(tD) * k.ct[q];
+    });
+    const uint64_t tot = sum4(HI);        // RN2: the 64-bit sum over the rows, two carry passes
+    const uint32_t w = ((uint32_t)tot & MASK) + from_prev((uint32_t)(tot >> W));
+    return (w & MASK) + from_prev(w >> W);
   }
 
   // Digit-serial Montgomery product (the scan of coop29.h on this layout, both rows doing the same work): result

@@ -54,6 +54,8 @@ def test_model_against_big_integers(moduli):
                 assert (L.value(r) * L.R - L.value(a) * L.value(b)) % L.p == 0, f
                 assert all(x <= L.M + 32 for x in r[:L.NL]) and all(x == 0 for x in r[L.NL:]), f
                 assert L.value(r) < (1 << 33) * L.p, f
+                if L.NL <= 13:      # the four-row form (one element per wavefront) gives the same LIMBS
+                    assert M.mul4(L, a, b) == r, f
 
 
 def test_bounds_of_a_round(moduli, params):
@@ -247,6 +249,10 @@ def run_asm(lines, opnd):
             if max(val) > M64:
                 raise M.Overflow(ln)
             put(args[0], val)
+        elif op == "v_permlane32_swap_b32":
+            a, b = get(args[0]), get(args[1])
+            put(args[0], a[:32] + b[:32])          # rows 2, 3 of vdst <-> rows 0, 1 of src0
+            put(args[1], a[32:] + b[32:])
         elif op == "v_permlane16_swap_b32":
             a, b = get(args[0]), get(args[1])
             na, nb = list(a), list(b)
@@ -311,13 +317,48 @@ def test_generated_assembly_on_the_lane_interpreter(moduli, field):
                 both_rows(r2, e, M.mul(L, want, b2[e]), ("sqr_mul", trial, n))
 
 
+@pytest.mark.parametrize("field", ["jubjub", "bn_254", "ed_on_bls12_377", "pallas"])
+def test_generated_four_row_assembly_on_the_lane_interpreter(moduli, field):
+    """One element on all four rows of the wavefront (11-limb fields): multiplication, squaring runs, fused steps."""
+    L = layouts(moduli)[field]
+    rng = random.Random(11)
+    Q4 = (L.NL + 3) // 4
+    names = {k: G.operand_names(L.NL, k, rows=4) for k in G.KINDS}
+    lines = {k: G.gen_product(L.NL, L.W, k, rows=4)[0] for k in G.KINDS}
+    ct = [[(L.C[4 * q + ((lane >> 4) & 3)] >> (L.W * (lane & 15))) & L.M if (4 * q + ((lane >> 4) & 3) < L.NL and (lane & 15) < L.NL) else 0
+           for lane in range(64)] for q in range(Q4)]
+
+    def run(kind, a, b=None, n=None):
+        nm = names[kind]
+        opnd = {nm["A"]: [a[lane & 15] for lane in range(64)]}
+        if b is not None:
+            opnd[nm["B"]] = [b[lane & 15] for lane in range(64)]
+        if n is not None:
+            opnd[nm["CNT"]] = n
+        opnd.update({nm["CT"][q]: ct[q] for q in range(Q4)})
+        r = run_asm(lines[kind], opnd)
+        assert r[0:16] == r[16:32] == r[32:48] == r[48:64], (field, kind)   # every row ends with the whole result
+        return r[0:16]
+
+    ops = operands(L, rng)
+    for trial in range(10):
+        a, b = ops[(trial * 3) % len(ops)], ops[(trial * 5 + 1) % len(ops)]
+        assert run("mul", a, b) == M.mul(L, a, b), (field, trial)
+        for n in (1, 3):
+            want = a
+            for _ in range(n):
+                want = M.mul(L, want, want)
+            assert run("sqr_run", a, n=n) == want, (field, trial, n)
+            assert run("sqr_mul", a, b, n=n) == M.mul(L, want, b), (field, trial, n)
+
+
 def test_hazard_distances_of_the_emitted_text():
     """Independent of the generator's padding: a VGPR written by a VALU instruction is not read through DPP (source or
     destination of a *_dpp instruction) or by v_permlane16_swap within the next two issue slots -- also across the
     back-edge of the squaring loop (checked by unrolling the body twice)."""
-    for nl, W in G.LAYOUTS:
+    for nl, W, rows in [(nl, W, r) for nl, W in G.LAYOUTS for r in ((2, 4) if nl <= 13 else (2,))]:
         for kind in G.KINDS:
-            lines = G.gen_product(nl, W, kind)[0]
+            lines = G.gen_product(nl, W, kind, rows)[0]
             # unroll every loop body twice so that the back-edges are checked as straight-line code (a forward branch
             # is checked as fall-through: its target sees at least the registers written before the branch)
             if "1:" in lines:
@@ -341,13 +382,13 @@ def test_hazard_distances_of_the_emitted_text():
                 sensitive = []
                 if op.endswith("_dpp"):
                     sensitive = flat[0] + flat[1]            # destination (old value) and the DPP source
-                elif op.startswith("v_permlane16_swap"):
+                elif op.startswith("v_permlane"):
                     sensitive = flat[0] + flat[1]
                 for r in sensitive:
                     if r in wrote:
                         assert slot - wrote[r] - 1 >= 2, (nl, kind, ln, r)
                 if op.startswith("v_"):
-                    written = flat[0] + (flat[1] if op.startswith("v_permlane16_swap") else [])
+                    written = flat[0] + (flat[1] if op.startswith("v_permlane") else [])
                     for r in written:
                         wrote[r] = slot
                 slot += 1

@@ -32,9 +32,10 @@ def rand_elems(oracle, fid, modulus, count, seed):
 
 
 # small batches take the cooperative latency kernels by default -- the two-row fold kernels (coop2d.h) for Anemoi-2-1,
-# the row-cooperative scan kernels for 4-3; "row" switches the two-row kernels off (2-1 on the row-cooperative scan
-# kernels), "lane" forces the lane-private throughput kernels
-LATENCY_KERNELS = {"default": {}, "row": {"coop2d_max": 0}, "lane": {"coop_max": 0, "coop2d_max": 0, "coop4_max": 0, "coop43_max": 0,
+# the row-cooperative scan kernels for 4-3; "row" switches the fold kernels off (2-1 on the row-cooperative scan
+# kernels), "lane" forces the lane-private throughput kernels.  (The one-item-per-wavefront kernels -- four-row fold /
+# scan -- are forced in test_cooperative_and_lane_private_paths_agree and in the fuzz.)
+LATENCY_KERNELS = {"default": {}, "row": {"coop_max": 0, "coop2d_max": 0}, "lane": {"coop_max": 0, "coop2d_max": 0, "coop4_max": 0, "coop43_max": 0,
                                            "coop_sponge_max": 0, "coop_climb_max": 0}}
 
 

@@ -168,6 +168,84 @@ def mul(L, a, b, trace=None):
     return r[0]
 
 
+# ---- four rows per element (11-limb fields only: the S form shifts b up by up to three lanes) ---------------------------
+def lanes4(fn, *regs):
+    return [[fn(*(r[h][l] for r in regs)) for l in range(16)] for h in range(4)]
+
+
+def swap16_4(vdst, src0):   # v_permlane16_swap on four rows: rows 1 <-> 0' and 3 <-> 2'
+    return [vdst[0], src0[0], vdst[2], src0[2]], [vdst[1], src0[1], vdst[3], src0[3]]
+
+
+def swap32_4(vdst, src0):   # v_permlane32_swap: rows 2, 3 of vdst <-> rows 0, 1 of src0
+    return [vdst[0], vdst[1], src0[0], src0[1]], [vdst[2], vdst[3], src0[2], src0[3]]
+
+
+def shr4(reg, n):
+    return [[r[l - n] if l - n >= 0 else 0 for l in range(16)] for r in reg]
+
+
+def shl4(reg, n):
+    return [[r[l + n] if l + n < 16 else 0 for l in range(16)] for r in reg]
+
+
+def mul4(L, a, b):
+    """The four-row form of mul(): one element per wavefront, row r multiplies by the limbs a_i with i = r (mod 4):
+    Q4 = ceil(NL / 4) steps per phase.  Same column layout (LO lane l = column l - OFF, HI lane l = column NL + l), the
+    sums over the rows take two swap levels (v_permlane16_swap, v_permlane32_swap)."""
+    W, NL, OFF, M = L.W, L.NL, L.OFF, L.M
+    assert NL <= 13, "row 3 holds b shifted up by three lanes"
+    Q4 = (NL + 3) // 4
+    A, B = [list(a)] * 4, [list(b)] * 4
+    aD = [shl4(A, r)[r] for r in range(4)]       # row r: lane l holds a_(l+r)
+    bS = [shr4(B, r)[r] for r in range(4)]       # row r: lane l holds b_(l-r)
+    LO = [[0] * 16 for _ in range(4)]
+    HI = [[0] * 16 for _ in range(4)]
+    for q in range(Q4):
+        Aq = [[r[4 * q]] * 16 for r in aD]
+        BL, BH = shr4(bS, OFF + 4 * q), shl4(bS, NL - 4 * q)
+        LO = lanes4(lambda t, x, y: chk(t + chk(x, 32, "a limb") * chk(y, 32, "b limb"), 64, "LO"), LO, Aq, BL)
+        HI = lanes4(lambda t, x, y: chk(t + x * y, 64, "HI"), HI, Aq, BH)
+    # RN1: sums over the four rows (cross-first)
+    lo = lanes4(lambda t: t & M, LO)
+    hi = lanes4(lambda t: chk(t >> W, 32, "LO >> W"), LO)
+    lo, hi = swap16_4(lo, hi)
+    s = lanes4(lambda x, y: chk(x + y, 32, "RN1 s"), lo, hi)          # rows: lo0+lo1, hi0+hi1, lo2+lo3, hi2+hi3
+    x = [list(r) for r in s]
+    s, x = swap32_4(s, x)
+    u = lanes4(lambda p, q_: chk(p + q_, 32, "RN1 u"), s, x)          # rows: sum lo, sum hi, sum lo, sum hi
+    y = [list(r) for r in u]
+    u, y = swap16_4(u, y)                                             # u = sum lo, y = sum hi, in all four rows
+    v = lanes4(lambda p, q_: chk(p + q_, 32, "RN1 v"), u, shr4(y, 1))
+    vh = lanes4(lambda p: p >> W, v)
+    cc = lanes4(lambda p, q_: chk(p + q_, 32, "RN1 cc"), y, vh)
+    t = lanes4(lambda p, q_: chk((p & M) + q_, 32, "RN1 t"), v, shr4(vh, 1))
+    assert cc[0][0] == cc[0][1] == cc[0][2] == 0                      # the injection reads lanes 15, 0, 1, 2 (row_ror:1, bank 0)
+    HI[0][0] = chk(HI[0][0] + cc[0][15], 64, "HI + cc")               # row 0 only: the rows are summed in RN2
+    tD = [shl4(t, r)[r] for r in range(4)]
+    # P2: fold
+    for q in range(Q4):
+        Lq = [[r[OFF + 4 * q]] * 16 for r in tD]
+        CT = [[(L.C[4 * q + h] >> (W * l)) & M if (4 * q + h < NL and l < NL) else 0 for l in range(16)] for h in range(4)]
+        HI = lanes4(lambda acc, p, c: chk(acc + chk(p, 32, "t limb") * c, 64, "HI fold"), HI, Lq, CT)
+    # RN2: the 64-bit sum over the four rows first
+    assert W <= 27
+    X = [list(r) for r in HI]
+    Hs, X = swap16_4(HI, X)
+    two = lanes4(lambda p, q_: chk(p + q_, 64, "RN2 pair sums"), Hs, X)
+    X = [list(r) for r in two]
+    Hs, X = swap32_4(two, X)
+    tot = lanes4(lambda p, q_: chk(p + q_, 64, "RN2 total"), Hs, X)
+    hi = lanes4(lambda p: chk(p >> W, 32, "total >> W"), tot)
+    if hi[0][15]:
+        raise Overflow("carry out of the top limb")
+    w = lanes4(lambda p, q_: chk((p & M) + q_, 32, "RN2 w"), tot, shr4(hi, 1))
+    wh = lanes4(lambda p: p >> W, w)
+    r = lanes4(lambda p, q_: (p & M) + q_, w, shr4(wh, 1))
+    assert r[0] == r[1] == r[2] == r[3]
+    return r[0]
+
+
 def selftest(seed=1, rounds=200):
     fields = {
         "bls12_381": 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
@@ -194,6 +272,8 @@ def selftest(seed=1, rounds=200):
                     a = L.limbs(rng.randrange(bound))
                     b = L.limbs(rng.randrange(bound))
                 r = mul(L, a, b)
+                if L.NL <= 13 and W <= 27:
+                    assert mul4(L, a, b) == r        # the four-row form gives the same LIMBS, not only the same value
                 va, vb, vr = L.value(a), L.value(b), L.value(r)
                 assert (vr * L.R - va * vb) % p == 0, (name, W, it)
                 assert all(x <= L.M + 32 for x in r[:L.NL]) and all(x == 0 for x in r[L.NL:]), (name, W, r)

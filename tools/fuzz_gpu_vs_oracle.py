@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzz of EVERY kernel family against the C oracle: random and structured states per field through
 
-  Jive 2-1      lane-private, two-row fold (coop2d), row-cooperative scan, one-item-per-wavefront scan
+  Jive 2-1      lane-private, two-row fold (coop2d), row-cooperative scan, one item per wavefront (four-row fold on the
+                11-limb fields, the scan on the 15-limb ones)
   Jive 4-3      lane-pair and row-cooperative, k = 2 and 4
   permutation   the default routing of the batch size
   sponge        two-row / row-cooperative / lane-private kernels on equal-length batches, the ragged kernel on all
@@ -85,7 +86,7 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
                     msg += "  row-coop(%d) %s" % (m, check((inst.compress_batch(st[:m]) == exp[:m]).all(), (field, width, "row-coop")))
                 m = min(cnt, 300)
                 with A.options(coop_max=BIG, coop2d_max=0, coop4_max=0):
-                    msg += "  wave-coop(%d) %s" % (m, check((inst.compress_batch(st[:m]) == exp[:m]).all(), (field, width, "wave-coop")))
+                    msg += "  one-per-wave(%d) %s" % (m, check((inst.compress_batch(st[:m]) == exp[:m]).all(), (field, width, "one-per-wave")))
             else:
                 exp4 = oracle.compress_batch(fid, 4, st, k=4, threads=threads)
                 with A.options(**LANE):
@@ -115,8 +116,8 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
                 if ln:
                     msgs[0], msgs[1] = 0, 255
                 exp = oracle.hash_bytes_batch(fid, width, msgs, threads=threads)
-                ok = ok and (inst.hash_batch(msgs) == exp).all()                      # default: two-row (2-1) / row-coop (4-3)
-                with A.options(coop2d_max=0):
+                ok = ok and (inst.hash_batch(msgs) == exp).all()                      # default: two-row fold (2-1), row-coop (4-3)
+                with A.options(coop_max=0, coop2d_max=0):
                     ok = ok and (inst.hash_batch(msgs) == exp).all()                  # row-cooperative sponge
                 with A.options(**LANE):
                     ok = ok and (inst.hash_batch(msgs) == exp).all()                  # lane-private sponge

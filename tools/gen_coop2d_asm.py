@@ -123,11 +123,11 @@ DPP_ODD = "row_mask:0xa bank_mask:0xf bound_ctrl:1"
 DPP_EVEN = "row_mask:0x5 bank_mask:0xf bound_ctrl:1"
 
 
-def operand_names(nl, kind):
+def operand_names(nl, kind, rows=2):
     """GCC operand numbers of a statement: outputs first (%0 = a in/out, then the SGPR run length of the statements
     that square), then the inputs: [b], the Q fold-table registers, [for 15 limbs: the limb mask with lane 15 all ones,
     and the mask that is all ones in lane 15 only]."""
-    Q = (nl + 1) // 2
+    Q = (nl + rows - 1) // rows
     names, k = {"A": "%0"}, 1
     if kind != "mul":
         names["CNT"], k = "%1", 2
@@ -319,16 +319,125 @@ class Gen:
         return P.lines, clob, info
 
 
-def gen_product(nl, W, kind):
+class Gen4(Gen):
+    """Four rows per element, ONE element per wavefront (11-limb fields: the S form shifts b up by up to three lanes, so
+    NL + 3 <= 16).  Row r multiplies by the limbs a_i with i = r (mod 4): Q4 = ceil(NL / 4) steps per phase -- half the
+    multiply-adds, broadcasts and shifts of the two-row form per wavefront, paid for with a second swap level
+    (v_permlane32_swap) in the two sums over the rows.  tools/coop2d_model.py::mul4 is the specification."""
+
+    def __init__(self, nl, W, kind):
+        super().__init__(nl, W, kind)
+        assert nl <= 13 and W <= 27
+        self.Q = (nl + 3) // 4
+        self.ops = operand_names(nl, kind, rows=4)
+
+    def product(self, a, b, out, shifts=None, ctl=(), after_hi=None):
+        P, R, nl, W, Q, OFF, MASK = self.P, self.P.reg, self.nl, self.W, self.Q, self.OFF, self.MASK
+        LO, HI, INJ = self.LO, self.HI, self.INJ
+        ctl = list(ctl)
+        row = lambda r: "row_mask:0x%x bank_mask:0xf bound_ctrl:1" % (1 << r)
+        AD = R("aD")
+        P.emit("v_mov_b32 %s, %s" % (AD, a), writes=[AD])
+        if ctl:
+            P.emit(ctl.pop(0), salu=True)
+        BS = None
+        if shifts is None:
+            BS = R("bS")          # a copy also when squaring: rewriting `a` in place would put a VALU write of `a` in
+            P.emit("v_mov_b32 %s, %s" % (BS, b or a), writes=[BS])   # front of every D-form read of it
+        # D form: row r lane l holds a_(l+r); S form: row r lane l holds b_(l-r).  The two registers are written
+        # alternately (a DPP destination is hazard-padded like a source), loop control in the gaps.
+        for r in (1, 2, 3):
+            P.emit("v_mov_b32_dpp %s, %s row_shl:%d %s" % (AD, a, r, row(r)), writes=[AD], sensitive=[a])
+            if shifts is None:
+                P.emit("v_mov_b32_dpp %s, %s row_shr:%d %s" % (BS, b or a, r, row(r)), writes=[BS], sensitive=[b or a])
+            if ctl:
+                P.emit(ctl.pop(0), salu=True)
+        while ctl:
+            P.emit(ctl.pop(0), salu=True)
+        if shifts is not None:
+            P.flush("pre")
+        for q in range(Q):
+            aq = R("a%d" % q)
+            P.emit("v_mov_b32_dpp %s, %s row_newbcast:%d %s" % (aq, AD, 4 * q, DPP_ALL), writes=[aq], sensitive=[AD])
+            if shifts is None:
+                bl, bh = R("bl%d" % (q & 1)), R("bh%d" % q)
+                P.emit("v_mov_b32_dpp %s, %s row_shr:%d %s" % (bl, BS, OFF + 4 * q, DPP_ALL), writes=[bl], sensitive=[BS])
+                assert 1 <= nl - 4 * q <= 15 and OFF + 4 * q <= 15
+                P.emit("v_mov_b32_dpp %s, %s row_shl:%d %s" % (bh, BS, nl - 4 * q, DPP_ALL), writes=[bh], sensitive=[BS])
+            else:
+                bl, bh = shifts[0][q], shifts[1][q]
+            P.emit("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (LO, aq, bl, LO if q else "0"), writes=[LO])
+            P.defer("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (HI, aq, bh, HI if q else "0"), writes=[HI], tag="hi")
+        if after_hi:
+            after_hi()
+        # ---- RN1: the low columns summed over the four rows (two swap levels), carried to limbs t in D form ----------
+        lo, hi, x, y = R("lo"), R("hi"), R("x"), R("y4")
+        vh, vl, cc, t = R("vh"), R("vl"), R("cc"), R("t")
+        P.emit("v_alignbit_b32 %s, %s, %s, %d" % (hi, P.hi("LO"), P.lo("LO"), W), writes=[hi])
+        P.emit("v_and_b32 %s, %s, %s" % (lo, MASK, P.lo("LO")), writes=[lo])
+        P.emit("v_permlane16_swap_b32 %s, %s" % (lo, hi), writes=[lo, hi], sensitive=[lo, hi])
+        P.emit("v_add_u32 %s, %s, %s" % (lo, lo, hi), writes=[lo])           # rows: lo0+lo1, hi0+hi1, lo2+lo3, hi2+hi3
+        P.emit("v_mov_b32 %s, %s" % (x, lo), writes=[x])
+        P.emit("v_permlane32_swap_b32 %s, %s" % (lo, x), writes=[lo, x], sensitive=[lo, x])
+        P.emit("v_add_u32 %s, %s, %s" % (lo, lo, x), writes=[lo])            # rows: sum lo, sum hi, sum lo, sum hi
+        P.emit("v_mov_b32 %s, %s" % (y, lo), writes=[y])
+        P.emit("v_permlane16_swap_b32 %s, %s" % (lo, y), writes=[lo, y], sensitive=[lo, y])   # lo = low parts, y = high parts
+        P.emit("v_add_u32_dpp %s, %s, %s row_shr:1 %s" % (hi, y, lo, DPP_ALL), writes=[hi], sensitive=[y])   # v
+        P.emit("v_lshrrev_b32 %s, %d, %s" % (vh, W, hi), writes=[vh])
+        P.emit("v_add_u32 %s, %s, %s" % (cc, y, vh), writes=[cc])
+        P.emit("v_and_b32 %s, %s, %s" % (vl, MASK, hi), writes=[vl])
+        P.emit("v_add_u32_dpp %s, %s, %s row_shr:1 %s" % (t, vh, vl, DPP_ALL), writes=[t], sensitive=[vh])
+        P.emit("v_mov_b32_dpp %s, %s row_ror:1 row_mask:0x1 bank_mask:0x1" % (P.lo("inj"), cc), writes=[P.lo("inj")], sensitive=[cc])
+        P.defer("v_lshl_add_u64 %s, %s, 0, %s" % (HI, HI, INJ), writes=[HI], tag="hi")
+        for r in (1, 2, 3):       # t in D form, in place
+            P.emit("v_mov_b32_dpp %s, %s row_shl:%d %s" % (t, t, r, row(r)), writes=[t], sensitive=[t])
+        # ---- P2 -------------------------------------------------------------------------------------------------------
+        tq = [R("a%d" % q) for q in range(Q)]
+        P.flush("hi")
+        for q in range(Q):
+            P.emit("v_mov_b32_dpp %s, %s row_newbcast:%d %s" % (tq[q], t, OFF + 4 * q, DPP_ALL), writes=[tq[q]], sensitive=[t])
+        for q in range(Q):
+            P.emit("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (HI, tq[q], self.ops["CT"][q], HI), writes=[HI])
+        # ---- RN2: the 64-bit sum over the four rows, two carry passes --------------------------------------------------
+        w, yh, yl = R("w"), R("yh"), R("yl")
+        X2 = R("X2", pair=True)
+        for swap in ("v_permlane16_swap_b32", "v_permlane32_swap_b32"):
+            P.emit("v_mov_b32 %s, %s" % (P.lo("X2"), P.lo("HI")), writes=[P.lo("X2")])
+            P.emit("v_mov_b32 %s, %s" % (P.hi("X2"), P.hi("HI")), writes=[P.hi("X2")])
+            P.emit("%s %s, %s" % (swap, P.lo("HI"), P.lo("X2")), writes=[P.lo("HI"), P.lo("X2")], sensitive=[P.lo("HI"), P.lo("X2")])
+            P.emit("%s %s, %s" % (swap, P.hi("HI"), P.hi("X2")), writes=[P.hi("HI"), P.hi("X2")], sensitive=[P.hi("HI"), P.hi("X2")])
+            P.emit("v_lshl_add_u64 %s, %s, 0, %s" % (HI, HI, X2), writes=[HI])
+        P.emit("v_alignbit_b32 %s, %s, %s, %d" % (hi, P.hi("HI"), P.lo("HI"), W), writes=[hi])
+        P.emit("v_and_b32 %s, %s, %s" % (lo, MASK, P.lo("HI")), writes=[lo])
+        P.emit("v_add_u32_dpp %s, %s, %s row_shr:1 %s" % (w, hi, lo, DPP_ALL), writes=[w], sensitive=[hi])
+        P.emit("v_lshrrev_b32 %s, %d, %s" % (yh, W, w), writes=[yh])
+        P.emit("v_and_b32 %s, %s, %s" % (yl, MASK, w), writes=[yl])
+        P.emit("v_add_u32_dpp %s, %s, %s row_shr:1 %s" % (out, yh, yl, DPP_ALL), writes=[out], sensitive=[yh])
+
+    def queue_operand_shifts(self, b):
+        P, R, nl, Q, OFF = self.P, self.P.reg, self.nl, self.Q, self.OFF
+        mbs = R("mbS")
+        P.defer("v_mov_b32 %s, %s" % (mbs, b), writes=[mbs], tag="pre")
+        for r in (1, 2, 3):
+            P.defer("v_mov_b32_dpp %s, %s row_shr:%d row_mask:0x%x bank_mask:0xf bound_ctrl:1" % (mbs, b, r, 1 << r),
+                    writes=[mbs], sensitive=[b], tag="pre")
+        bl, bh = [R("mbl%d" % q) for q in range(Q)], [R("mbh%d" % q) for q in range(Q)]
+        for q in range(Q):
+            P.defer("v_mov_b32_dpp %s, %s row_shr:%d %s" % (bl[q], mbs, OFF + 4 * q, DPP_ALL), writes=[bl[q]], sensitive=[mbs], tag="pre")
+            P.defer("v_mov_b32_dpp %s, %s row_shl:%d %s" % (bh[q], mbs, nl - 4 * q, DPP_ALL), writes=[bh[q]], sensitive=[mbs], tag="pre")
+        return bl, bh
+
+
+def gen_product(nl, W, kind, rows=2):
     """-> (lines, clobbers, info) of the statement `kind` in KINDS"""
-    return Gen(nl, W, kind).build()
+    return (Gen4 if rows == 4 else Gen)(nl, W, kind).build()
 
 
-def render(nl, W):
-    Q = (nl + 1) // 2
+def render(nl, W, rows=2):
+    Q = (nl + rows - 1) // rows
     out = []
     for kind in KINDS:
-        lines, clob, info = gen_product(nl, W, kind)
+        lines, clob, info = gen_product(nl, W, kind, rows)
         body = "\n".join('        "%s\\n\\t"' % l for l in lines)
         outs = ['"+v"(a)'] + (['"+s"(n)'] if kind != "mul" else [])
         ins = (['"v"(b)'] if kind != "sqr_run" else []) + ['"v"(ct[%d])' % q for q in range(Q)]
@@ -355,20 +464,22 @@ def main():
          "// squarings followed by a multiplication (one exponentiation step), the loops inside the statements.",
          "// Layout-driven (limbs, limb bits): the fold table arrives as operands.",
          "#pragma once", "#include <hip/hip_runtime.h>", "#include <cstdint>", "namespace anemoi {",
-         "template <int NL, int W> struct AsmCoop2d;"]
+         "template <int NL, int W, int ROWS = 2> struct AsmCoop2d;   // ROWS 16-lane rows per element"]
     for nl, W in LAYOUTS:
-        h.append("template <> struct AsmCoop2d<%d, %d> {" % (nl, W))
-        h += render(nl, W)
-        h.append("};")
+        for rows in ((2, 4) if nl <= 13 else (2,)):
+            h.append("template <> struct AsmCoop2d<%d, %d, %d> {" % (nl, W, rows))
+            h += render(nl, W, rows)
+            h.append("};")
     h.append("}  // namespace anemoi")
     dst = os.path.join(ROOT, "anemoi-rust_amd", "csrc", "coop2d_asm_gen.h" if PAD_DPP_DST else "coop2d_asm_gen_novdst.h")
     with open(dst, "w") as f:
         f.write("\n".join(h) + "\n")
     print("wrote", dst)
     for nl, W in LAYOUTS:
-        for kind in KINDS:
-            _, _, info = gen_product(nl, W, kind)
-            print("  %2d limbs of %d bits, %-8s %s" % (nl, W, kind, {k: v for k, v in info.items() if k in ("slots", "last_sqr_plus_mul_slots", "nops")}))
+        for rows in ((2, 4) if nl <= 13 else (2,)):
+            for kind in KINDS:
+                _, _, info = gen_product(nl, W, kind, rows)
+                print("  %2d limbs of %d bits, %d rows, %-8s %s" % (nl, W, rows, kind, {k: v for k, v in info.items() if k in ("slots", "last_sqr_plus_mul_slots", "nops")}))
 
 
 if __name__ == "__main__":

@@ -311,6 +311,17 @@ def fold_struct(fl, p, L, g, delta, i21, i43):
             ck = ((1 << (W * k)) * rinv) % p if k < NL else 0
             tab += limbsw(ck) + [0] * (16 - NL)
     s.append("    static constexpr uint32_t FoldT[%d] = %s;" % (len(tab), c32(tab)))
+    # the same table for FOUR rows per element (row r takes the limbs k = r mod 4): word [(q * 4 + r) * 16 + l] = limb l of
+    # C_(4q+r).  11-limb fields only: the four-row S form shifts an operand up by three lanes (NL + 3 <= 16).
+    Q4 = (NL + 3) // 4 if NL <= 13 else 0
+    tab4 = []
+    for qq in range(Q4):
+        for rr in range(4):
+            k = 4 * qq + rr
+            ck = ((1 << (W * k)) * rinv) % p if k < NL else 0
+            tab4 += limbsw(ck) + [0] * (16 - NL)
+    s.append("    static constexpr int Q4 = %d;   // steps per phase of the four-row form (0: not built for this field)" % Q4)
+    s.append("    static constexpr uint32_t FoldT4[%d] = %s;" % (max(len(tab4), 1), c32(tab4 or [0])))
     for nm, inst in (("21", i21), ("43", i43)):
         for cd in ("c", "d"):
             vals = []
