@@ -154,9 +154,25 @@ inline std::vector<size_t> ragged_order(const uint64_t* off, size_t n, size_t bl
     given += (unsigned long long)mx * cnt;   // (the idle lanes of a partly filled last wavefront are nobody's fault)
   }
   if (given - total <= given / 32) return order;   // at most ~3 % of the lanes' block-steps idle: leave it
+  // stable, by descending block count: a counting sort when the counts span a small range (the usual case: O(n), a
+  // 2^19-message batch in ~2 ms where a comparison sort takes ~100 ms before the first chunk can be staged)
+  std::vector<size_t> key(n);
+  size_t lo = ~size_t(0), hi = 0;
+  for (size_t i = 0; i < n; i++) {
+    key[i] = blocks(i);
+    lo = key[i] < lo ? key[i] : lo;
+    hi = key[i] > hi ? key[i] : hi;
+  }
   order.resize(n);
-  for (size_t i = 0; i < n; i++) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return blocks(a) > blocks(b); });
+  if (hi - lo < (size_t(1) << 22)) {
+    std::vector<size_t> start(hi - lo + 2, 0);
+    for (size_t i = 0; i < n; i++) start[hi - key[i] + 1]++;          // bucket 0 = the longest messages
+    for (size_t b = 1; b < start.size(); b++) start[b] += start[b - 1];
+    for (size_t i = 0; i < n; i++) order[start[hi - key[i]]++] = i;
+  } else {
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key[a] > key[b]; });
+  }
   return order;
 }
 

@@ -321,7 +321,9 @@ def main():
                     # 1 would mean the instruction count or the peak model is wrong and is flagged
                     "valu_instr_per_item": valu_per_item,
                     "valu_issue_frac": (valu_per_item * n / (kernel_ms * 1e-3) / peak_lane_ops) if valu_per_item else None,
-                    "valu_issue_inconsistent": bool(valu_per_item and valu_per_item * n / (kernel_ms * 1e-3) / peak_lane_ops > 1.0),
+                    # (> 1.005: half a per cent for the counter's own granularity; round 4's boxes land at 0.98-1.00, i.e.
+                    # the vector ALUs issue in every cycle the maximum clock has)
+                    "valu_issue_inconsistent": bool(valu_per_item and valu_per_item * n / (kernel_ms * 1e-3) / peak_lane_ops > 1.005),
                     "note": "v_mad_u64_u32 lane-operations per second (count per compression from the generated assembly and "
                             "exponent schedule: 21 rounds x (%d squarings x %d + %d multiplications x %d) + 5 x %d) against "
                             "1024 SIMDs x 16 lanes per clock at 2.4 GHz; the path is VALU-bound, see DESIGN.md"

@@ -6,7 +6,7 @@
 #   pmc_fetch/ pmc_write/ pmc_sq/   three separate --pmc passes (never combined with trace domains)
 #   tools/collect_config_profiles.sh <tag>
 set -o pipefail
-tag="${1:-r03}"
+tag="${1:-r04}"
 out="gpurun_out/prof_cfg_${tag}"
 mkdir -p "$out"
 export TMPDIR=/tmp

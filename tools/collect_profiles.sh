@@ -6,13 +6,13 @@
 # then tools/summarize_profiles.py turns them into the files kept under profiles/rNN/.
 #   tools/collect_profiles.sh <tag>
 set -o pipefail
-tag="${1:-r03}"
+tag="${1:-r04}"
 out="gpurun_out/prof_${tag}"
 mkdir -p "$out"
 export TMPDIR=/tmp
 BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 # a first bench line for the summariser (batch size, kernel time); the judged line is taken at the end, after the
-# fresh counter summary is in place, so that its roofline.traffic / alu.valu_util refer to THIS build
+# fresh counter summary is in place, so that its roofline.traffic / alu.valu_issue_frac refer to THIS build
 python bench.py --no-cpu-baseline --steps 2 > "$out/bench_n1.json" 2> "$out/bench_n1.err" || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o run -- $BENCH > "$out/stats.log" 2>&1 || exit 1
 PMC="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"

@@ -61,8 +61,8 @@ def counters(d):
 
 
 def items_per_wave(kernel):
-    if "coop" in kernel:
-        return 4 if kernel.endswith(", 16>") else 1     # row-cooperative: four items per wavefront
+    if "coop" in kernel:   # row-cooperative scan: four items per wavefront; two-row fold: two; one item per wavefront else
+        return 4 if kernel.endswith(", 16>") else (2 if kernel.endswith(", 32>") else 1)
     return 32 if ("_pair" in kernel) else 64
 
 
@@ -139,16 +139,19 @@ def main():
         summary["cfg3_ms"] = sp["kernel_ms_min_stats_pass"]
         summary["cfg3_fraction_of_flat_rate"] = perm_rate / summary["flat_bn254_4_3_M_per_s"]
     if flat_j:
-        # the depth-21 tree: levels of 2^20 .. 2^14 nodes on k_jive (grid = nodes), 2^13 .. 1 on the row-cooperative
-        # kernel (four nodes per wavefront: grid = ceil(nodes / 4) * 64)
+        # the depth-21 tree: levels of 2^20 .. 2^14 nodes on k_jive (grid = nodes), 2^13 and 2^12 on the row-cooperative
+        # scan kernel (four nodes per wavefront: grid = ceil(nodes / 4) * 64), 2^11 .. 1 on the two-row fold kernel (two
+        # nodes per wavefront)
         tree_ms = 0.0
         levels = []
         for l in range(21):
             nodes = 1 << (20 - l)
             if nodes > 8192:
                 r = med("k_jive<4, 2, 2>", lambda g, nodes=nodes: g == nodes)
-            else:
+            elif nodes > 2048:
                 r = med("k_jive2_coop<4, 16>", lambda g, nodes=nodes: g == (nodes + 3) // 4 * 64)
+            else:
+                r = med("k_jive2_coop<4, 32>", lambda g, nodes=nodes: g == (nodes + 1) // 2 * 64)
             if r:
                 levels.append({"nodes": nodes, "kernel": r["kernel"], "ms": r["kernel_ms_min_stats_pass"],
                                "avg_waves_per_SIMD": r.get("avg_waves_per_SIMD")})
