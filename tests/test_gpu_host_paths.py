@@ -1,7 +1,7 @@
 """The host-pointer entry points that round 2 left outside the chunked pipeline -- the ragged sponge, batched
 path verification (binary and arity 4) and the run-time instances -- now go through rt::pipeline_staged
 (csrc/runtime.h): chunks cut at message / item boundaries, three chunks resident on the device.  These
-tests force MANY small chunks (ANEMOI_CHUNK_TARGET_BYTES, ANEMOI_TEST_QUANTUM: both read at every call) so
+tests force MANY small chunks (options chunk_target_bytes, test_quantum: anemoi_set_option) so
 that the three-slot ring wraps several times, in both staging modes, and compare every result with the
 oracle (reference semantics: src/<f>/anemoi_*/hasher.rs:19-91 for the sponge, :86-92 for merge, :162-179 for
 compress_k).  Bit-exact.  Run on the GPU box: pytest -m gpu.
