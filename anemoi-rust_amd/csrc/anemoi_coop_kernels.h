@@ -99,23 +99,19 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typ
     // then waits for it in front of the products)
     typedef const volatile uint32_t __attribute__((address_space(3))) * LdsWords;
     const LdsWords vtab = (LdsWords)(uintptr_t)tab;   // (tab is __shared__: the low 32 bits of the flat address are the LDS offset)
-    auto operand_of = [&](uint32_t w) {
-      const uint32_t i = w >> 8;
-      return vtab[(i < uint32_t(E) ? i : 0u) * kBlock + lane];
-    };
+    // operand address = table base + (idx << 8) bytes = word & 0xff00 (an entry is kBlock = 64 words), masked to the
+    // table so that the markers 253..255 read a harmless entry instead of being branched around
+    static_assert(kBlock == 64, "idx << 8 is the byte offset of table entry idx");
+    auto operand_of = [&](uint32_t w) { return vtab[((w & (uint32_t(E - 1) << 8)) >> 2) + lane]; };
     uint32_t word = uniform_word(pc.sched5, 0), next = uniform_word(pc.sched5, 1);
     uint32_t opnd = operand_of(word);
-#pragma nounroll
-    for (int s = 0; s < pc.steps5; s++) {
-      const uint32_t after = uniform_word(pc.sched5, s + 2);
-      const uint32_t opnd_next = operand_of(next);
-      const uint32_t nsq = word & 0xff, idx = word >> 8;
-      uint32_t b = opnd;
-      word = next, next = after, opnd = opnd_next;
+    // one general step: decode, the tmp-register operations of the leading-run doubling, squarings and / or a multiplication
+    auto general_step = [&](uint32_t w, uint32_t b) {
+      const uint32_t nsq = w & 0xff, idx = w >> 8;
       if constexpr (F::kChainTmp) {
         if (idx == 253) {  // leading-run doubling, see sliding_window() in tools/gen_params.py
           tmp = acc;
-          continue;
+          return;
         }
         b = idx == 254 ? tmp : b;
       }
@@ -126,6 +122,27 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typ
       } else {
         acc = C::mul(acc, b, k);
       }
+    };
+    constexpr int kGeneral = F::kCoopRegular ? F::kCoopPrefix : 1 << 30;   // steps that go through the general form
+    int s = 0;
+#pragma nounroll
+    for (; s < pc.steps5 && s < kGeneral; s++) {
+      const uint32_t after = uniform_word(pc.sched5, s + 2);
+      const uint32_t opnd_next = operand_of(next);
+      general_step(word, opnd);
+      word = next, next = after, opnd = opnd_next;
+    }
+    if constexpr (F::kCoopRegular) {
+      // the regular tail, every step but the last: squarings, then a table multiplication -- no decoding, no branches
+#pragma nounroll
+      for (; s < pc.steps5 - 1; s++) {
+        const uint32_t after = uniform_word(pc.sched5, s + 2);
+        const uint32_t opnd_next = operand_of(next);
+        acc = C::sqr_mul(acc, word & 0xff, opnd, k);
+        word = next, next = after, opnd = opnd_next;
+      }
+      if ((word >> 8) == 255) acc = C::sqr_n(acc, word & 0xff, k);   // the trailing squarings of the exponent
+      else acc = C::sqr_mul(acc, word & 0xff, opnd, k);
     }
     t = acc;
   }

@@ -473,7 +473,22 @@ def main():
             h.append("  static constexpr int kW%dFirst = %d, kW%dSteps = %d;" % (k, first, k, len(steps)))
             h.append("  static constexpr uint8_t kW%dSched[%d] = {%s};" % (k, len(flat), ",".join(map(str, flat))))
         h.append("  // cheapest window for the wave-cooperative kernels (a table entry costs them one LDS word per lane)")
-        h.append("  static constexpr int kCoopWin = %d;" % min(cost, key=cost.get))
+        coop_win = min(cost, key=cost.get)
+        h.append("  static constexpr int kCoopWin = %d;" % coop_win)
+        _, csteps = sliding_window(e, coop_win)
+        # A schedule is [prefix of leading-run doubling steps (253 / 254)] + [a regular tail]: every tail step is >= 1
+        # squarings and then a table multiplication, except that the last may be squarings only.  The cooperative S-box
+        # runs the prefix through its general step loop and the tail through a branch-free one (anemoi_coop_kernels.h).
+        prefix = 0
+        while prefix < len(csteps) and csteps[prefix][1] in (253, 254):
+            prefix += 1
+        tail = csteps[prefix:]
+        regular = (len(tail) >= 2 and all(s_ >= 1 and t_ < 253 for s_, t_ in tail[:-1]) and tail[-1][0] >= 1 and
+                   (tail[-1][1] < 253 or tail[-1][1] == 255))
+        h.append("  // the kCoopWin schedule = kCoopPrefix leading-run doubling steps + a tail that is \"regular\" (>= 1 squarings, then a")
+        h.append("  // table multiplication; the last step may be squarings only): the cooperative S-box runs the tail branch-free")
+        h.append("  static constexpr int kCoopPrefix = %d;" % prefix)
+        h.append("  static constexpr bool kCoopRegular = %s;" % ("true" if regular else "false"))
         h.append("  static constexpr bool kChainTmp = %s;  // the schedules use the tmp register (ops 253 / 254)" % (
             "true" if uses_tmp else "false"))
         # window-3 table + extra digits held in VGPRs (anemoi_perm.h exp_inv_alpha); not for the fields whose exponent
