@@ -146,7 +146,7 @@ def release(device=ALL_DEVICES):
 
 
 OPTIONS = ("coop_max", "coop2d_max", "coop4_max", "coop43_max", "coop_sponge_max", "coop_climb_max",
-           "merkle_subtrees_log2", "virtual_devices", "host_staging", "chunk_target_bytes", "test_quantum",
+           "virtual_devices", "host_staging", "chunk_target_bytes", "test_quantum",
            "sponge_segment_bytes")
 AUTO = -1
 

@@ -26,7 +26,6 @@ enum Id {
   kCoop43Max,           // largest Jive 4-3 / permutation batch on the row-cooperative 4-3 kernel (two states per wavefront)
   kCoopSpongeMax,       // largest equal-length sponge batch on k_sponge_coop
   kCoopClimbMax,        // largest batch of authentication paths on k_merkle_climb_coop
-  kMerkleSubtrees,      // log2 of the number of subtrees a device-resident Merkle build climbs on separate streams (auto: by depth; 0 = one stream)
   kTestQuantum,         // items per "full wave of workgroups" of the chunked host pipelines (auto: occupancy API)
   kChunkTargetBytes,    // input bytes per chunk of the host pipelines (auto: 24 MiB)
   kSpongeSegmentBytes,  // forces the segment-fed sponge with this many bytes per segment (auto: by batch shape)
@@ -49,7 +48,6 @@ inline const Spec& spec(int id) {
       {"coop43_max", "ANEMOI_COOP43_MAX", 0, 1ll << 62},
       {"coop_sponge_max", "ANEMOI_COOP_SPONGE_MAX", 0, 1ll << 62},
       {"coop_climb_max", "ANEMOI_COOP_CLIMB_MAX", 0, 1ll << 62},
-      {"merkle_subtrees_log2", "ANEMOI_MERKLE_SUBTREES_LOG2", 0, 6},
       {"test_quantum", "ANEMOI_TEST_QUANTUM", 1, 1ll << 40},
       {"chunk_target_bytes", "ANEMOI_CHUNK_TARGET_BYTES", 1, 1ll << 40},
       {"sponge_segment_bytes", "ANEMOI_SPONGE_SEGMENT_BYTES", 1, 1ll << 40},

@@ -112,9 +112,6 @@ int anemoi_release(int device);
  *   coop_sponge_max        ANEMOI_COOP_SPONGE_MAX       4 x SIMDs                      largest equal-length sponge batch on the cooperative kernel
  *   coop_climb_max         ANEMOI_COOP_CLIMB_MAX        4 x SIMDs                      largest batch of authentication paths on the cooperative kernel
  *   coop_max               ANEMOI_COOP_MAX              0                              one-item-per-wavefront scan kernel (A/B and parity only)
- *   merkle_subtrees_log2   ANEMOI_MERKLE_SUBTREES_LOG2  by depth                       a device-resident Merkle build climbs 2^v subtrees on
- *                                                                                      separate streams (narrow levels of one under the wide levels of
- *                                                                                      another); 0 = level by level on one stream
  *   virtual_devices        ANEMOI_VIRTUAL_DEVICES       the GPU count                  ANEMOI_ALL_DEVICES shards into this many ranges / subtrees,
  *                                                                                      mapped round-robin onto the GPUs (multi-GPU code on one GPU)
  *   host_staging           ANEMOI_HOST_STAGING          1 ("pinned")                   1: host buffers go through the lane's pinned staging;

@@ -194,9 +194,10 @@ def run_asm(lines, opnd):
         pc += 1
         steps += 1
         assert steps < 100000
-        if ln.endswith(":") or ln.startswith("s_nop"):
+        if ln.endswith(":") or ln.startswith("s_nop") or ln.startswith(".p2align") or ln.startswith("v_nop"):
             continue
         op, _, rest = ln.partition(" ")
+        op = re.sub(r"_e(32|64)$", "", op)          # the encoding (4 / 8 bytes) is layout, not semantics
         ctrl = None
         m = re.search(r"\s(row_(?:shr|shl|ror|newbcast):.*)$", rest)
         if m:
@@ -211,6 +212,8 @@ def run_asm(lines, opnd):
         elif op == "s_cbranch_scc1":
             if scc:
                 pc = labels[args[0][:-1]]       # "1b" / "2f" -> label "1" / "2"
+        elif op == "s_branch":
+            pc = labels[args[0][:-1]]
         elif op == "v_mov_b32":
             put(args[0], get(args[1]))
         elif op == "v_mov_b32_dpp":
@@ -344,7 +347,7 @@ def test_generated_four_row_assembly_on_the_lane_interpreter(moduli, field):
     for trial in range(10):
         a, b = ops[(trial * 3) % len(ops)], ops[(trial * 5 + 1) % len(ops)]
         assert run("mul", a, b) == M.mul(L, a, b), (field, trial)
-        for n in (1, 3):
+        for n in (1, 3) + ((G.UNROLL, G.UNROLL + 2) if trial < 2 else ()):   # (the longer runs wrap round the unrolled copies)
             want = a
             for _ in range(n):
                 want = M.mul(L, want, want)
@@ -359,12 +362,13 @@ def test_hazard_distances_of_the_emitted_text():
     for nl, W, rows in [(nl, W, r) for nl, W in G.LAYOUTS for r in ((2, 4) if nl <= 13 else (2,))]:
         for kind in G.KINDS:
             lines = G.gen_product(nl, W, kind, rows)[0]
-            # unroll every loop body twice so that the back-edges are checked as straight-line code (a forward branch
-            # is checked as fall-through: its target sees at least the registers written before the branch)
-            if "1:" in lines:
-                i0 = lines.index("1:")
-                i1 = lines.index("s_cbranch_scc1 1b")
-                lines = lines[:i0] + lines[i0 + 1:i1 + 1] + lines[i0 + 1:]
+            # A run of squarings is already laid out as UNROLL >= 2 copies of the body, each followed by an exit branch:
+            # read as straight-line code that checks body -> body (which is also the back-edge: `s_branch 1b` leads from
+            # the last copy to the first) and, without the s_branch, last body -> exit branch -> what follows the run
+            # (every copy ends the same way, so that is every exit).  A forward branch is checked as fall-through: its
+            # target sees at least the registers written before the branch.
+            assert G.UNROLL >= 2
+            lines = [l for l in lines if not l.startswith(".p2align") and not l.startswith("s_branch")]
             lines = [l for l in lines if not l.endswith(":")]
             slot, wrote = 0, {}
             for ln in lines:
@@ -374,6 +378,10 @@ def test_hazard_distances_of_the_emitted_text():
                     continue
                 if ln.endswith(":"):
                     continue
+                if op.startswith("v_nop"):
+                    slot += 1
+                    continue
+                op = re.sub(r"_e(32|64)$", "", op)
                 regs = re.findall(r"v\[\d+:\d+\]|v\d+|%\d+", rest.split(" row_")[0])
                 flat = []
                 for r in regs:
@@ -392,6 +400,39 @@ def test_hazard_distances_of_the_emitted_text():
                     for r in written:
                         wrote[r] = slot
                 slot += 1
+
+
+def test_statements_sit_on_the_8_byte_fetch_grid():
+    """A lone wavefront pays ~1 cycle for every 8-byte instruction that straddles an 8-byte boundary
+    (tools/ubench/lone_wave_fetch.hip), so the generator lays the statements out on an 8-byte grid.  Checked with the
+    assembler itself: every line's encoded size is what the generator assumed, and every 8-byte instruction starts at a
+    multiple of 8 from the statement's (aligned) start -- with no padding instruction inserted to get there."""
+    import shutil
+    import subprocess
+    mc = shutil.which("llvm-mc") or "/opt/rocm/lib/llvm/bin/llvm-mc"
+    if not os.path.exists(mc):
+        pytest.skip("no llvm-mc")
+    for nl, W, rows in [(nl, W, r) for nl, W in G.LAYOUTS for r in ((2, 4) if nl <= 13 else (2,))]:
+        for kind in G.KINDS:
+            lines, _, info = G.gen_product(nl, W, kind, rows)
+            assert info["inserted_for_alignment"] == 0, (nl, kind)
+            assert lines[0] == ".p2align 3"
+            cnt = G.operand_names(nl, kind, rows).get("CNT")
+            text = []
+            for ln in lines:
+                if cnt:
+                    ln = re.sub(re.escape(cnt) + r"(?!\d)", "s40", ln)
+                text.append(re.sub(r"%(\d+)", lambda m: "v%d" % (200 + int(m.group(1))), ln))
+            out = subprocess.run([mc, "-triple=amdgcn-amd-amdhsa", "-mcpu=gfx950", "-show-encoding"],
+                                 input="\n".join(text) + "\n", capture_output=True, text=True, check=True).stdout
+            sizes = [len(m.group(1).split(",")) for m in re.finditer(r"encoding: \[([^\]]*)\]", out)]
+            insts = [ln for ln in lines if not ln.endswith(":") and not ln.startswith(".")]
+            assert len(sizes) == len(insts), (nl, kind, len(sizes), len(insts))
+            off = 0
+            for ln, size in zip(insts, sizes):
+                assert size == G.enc_size(ln), (nl, kind, ln, size)
+                assert size == 4 or off % 8 == 0, (nl, kind, ln, off)
+                off += size
 
 
 def test_committed_header_is_what_the_generator_writes():

@@ -161,3 +161,29 @@ def test_unsorted_ragged_batch_is_bucketed_by_length_inside_the_library(A, oracl
         assert (got == many).all() and (got == shard).all(), (field, width)
         for i in list(range(0, n, 11)) + [int(np.argmax(lens)), int(np.argmin(lens))]:
             assert (got[i] == oracle.hash_bytes(fid, width, msgs[i])).all(), (field, width, i, int(lens[i]))
+
+
+def test_few_long_messages_stay_segmented_and_bound_the_device_footprint(A, oracle):
+    """A batch that is SMALL by count (<= the cooperative sponge's cut-off) but LARGE by bytes -- 4 096 messages of
+    64 KiB, 256 MiB -- must stream through the segment-fed sponge (three resident segments of ~24 MiB plus the carried
+    states), not ride the single-launch latency route with the whole batch on the device and in pinned staging (round
+    3's routing did, see capi.hip `latency_batch`).  Asserted on what the device actually holds after the call
+    (hipMemGetInfo before / after, from a released library), and on sampled digests against the oracle."""
+    import torch
+    field, width = "bn_254", 4
+    fid, inst = FIELD_IDS.index(field), A.Anemoi(field, width)
+    n, ln = 4096, 64 * 1024 + 17          # a ragged tail in the last block of every message
+    total = n * ln
+    assert n <= 4 * 1024 and total > (200 << 20)
+    msgs = np.random.default_rng(77).integers(0, 256, size=(n, ln), dtype=np.uint8)
+    A.release(0)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    got = inst.hash_batch(msgs)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    held = free0 - free1                   # the lane keeps its buffers until anemoi_release: this is the call's footprint
+    assert 0 < held < (120 << 20), "device footprint %.1f MiB for a %.0f MiB batch" % (held / 2**20, total / 2**20)
+    for i in (0, 1, n // 2, n - 1):
+        assert (got[i] == oracle.hash_bytes(fid, width, msgs[i].tobytes())).all(), i
+    A.release(0)

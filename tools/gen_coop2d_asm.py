@@ -26,13 +26,21 @@ independently.
 """
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VBASE = 80          # clobbered VGPRs v[VBASE ...] (even: 64-bit pairs are 2-aligned)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from asm_grid import align8, enc_size  # noqa: E402,F401
+
 LAYOUTS = [(11, 27), (15, 28)]   # (limbs, limb bits) of the fold layouts in field_consts_gen.h
 KINDS = ("mul", "sqr_run", "sqr_mul")
 # A/B only: ANEMOI_COOP2D_GEN_NOVDST=1 writes csrc/coop2d_asm_gen_novdst.h without the padding of DPP destinations
 PAD_DPP_DST = os.environ.get("ANEMOI_COOP2D_GEN_NOVDST") != "1"
+# copies of the product in a run of squarings (one taken branch per run, not per squaring) and the alignment of the
+# branch target behind it; the environment variables are for A/B builds only
+UNROLL = int(os.environ.get("ANEMOI_COOP2D_GEN_UNROLL", "8"))
+ALIGN_LOG2 = int(os.environ.get("ANEMOI_COOP2D_GEN_ALIGN", "5"))
 
 
 class Prog:
@@ -112,10 +120,13 @@ class Prog:
             self.emit(f[0], writes=f[1], sensitive=f[2])
         self.pending = keep
 
-    def label(self, name):
-        self.lines.append(name + ":")
+    def barrier(self):
         for r in list(self.wrote):           # every predecessor: assume everything was written in the previous slot
             self.wrote[r] = self.slot - 1
+
+    def label(self, name):
+        self.lines.append(name + ":")
+        self.barrier()
 
 
 DPP_ALL = "row_mask:0xf bank_mask:0xf bound_ctrl:1"
@@ -163,7 +174,7 @@ class Gen:
         ctl = list(ctl)
         AD = R("aD")
         P.emit("v_mov_b32 %s, %s" % (AD, a), writes=[AD])
-        if ctl:
+        while ctl:                           # (together: a pair of 4-byte SALU instructions stays on the 8-byte fetch grid)
             P.emit(ctl.pop(0), salu=True)
         BS = None
         if shifts is None:
@@ -279,6 +290,25 @@ class Gen:
             P.defer("v_mov_b32_dpp %s, %s row_shl:%d %s" % (bh[q], mbs, nl - 2 * q, DPP_ALL), writes=[bh[q]], sensitive=[mbs], tag="pre")
         return bl, bh
 
+    def squarings(self, A, CNT, done, info):
+        """CNT (>= 1) squarings of A, then on to label `done` (which follows).  A taken branch costs a lone wavefront an
+        instruction refetch -- tens of cycles, more when the target sits at the end of a fetch line (measured: aligning
+        the loop head alone was worth 2-7 %) -- so the run is UNROLL copies of the product, each followed by an exit
+        branch that is NOT taken until the count is used up: one taken branch per run instead of one per squaring.
+        Runs longer than UNROLL go round; `done` is aligned to a fetch line (the padding is jumped over)."""
+        P = self.P
+        P.label("1")
+        for u in range(UNROLL):
+            if u:
+                P.barrier()
+            s0 = P.slot
+            self.product(A, None, A, ctl=["s_sub_u32 %s, %s, 1" % (CNT, CNT), "s_cmp_eq_u32 %s, 0" % CNT])
+            P.emit("s_cbranch_scc1 %sf" % done, salu=True)
+            if not u:
+                info["slots"] = P.slot - s0
+        P.emit("s_branch 1b", salu=True)
+        P.lines.append(".p2align %d" % ALIGN_LOG2)
+
     def build(self):
         P, ops, kind = self.P, self.ops, self.kind
         A, B, CNT = ops["A"], ops.get("B"), ops.get("CNT")
@@ -293,20 +323,13 @@ class Gen:
             self.product(A, B, A)
             info["slots"] = P.slot - s0
         elif kind == "sqr_run":
-            P.label("1")
-            s0 = P.slot
-            self.product(A, None, A, ctl=["s_sub_u32 %s, %s, 1" % (CNT, CNT), "s_cmp_lg_u32 %s, 0" % CNT])
-            P.emit("s_cbranch_scc1 1b", salu=True)
-            info["slots"] = P.slot - s0
-        else:  # sqr_mul: n - 1 squarings in the loop, the last one carries the multiplication's operand shifts
+            self.squarings(A, CNT, "9", info)
+            P.label("9")
+        else:  # sqr_mul: n - 1 squarings, then the last one, which carries the multiplication's operand shifts
             P.emit("s_sub_u32 %s, %s, 1" % (CNT, CNT), salu=True)
             P.emit("s_cmp_eq_u32 %s, 0" % CNT, salu=True)
             P.emit("s_cbranch_scc1 2f", salu=True)
-            P.label("1")
-            s0 = P.slot
-            self.product(A, None, A, ctl=["s_sub_u32 %s, %s, 1" % (CNT, CNT), "s_cmp_lg_u32 %s, 0" % CNT])
-            P.emit("s_cbranch_scc1 1b", salu=True)
-            info["slots"] = P.slot - s0
+            self.squarings(A, CNT, "2", info)
             P.label("2")
             s1 = P.slot
             shifts = {}
@@ -338,7 +361,7 @@ class Gen4(Gen):
         row = lambda r: "row_mask:0x%x bank_mask:0xf bound_ctrl:1" % (1 << r)
         AD = R("aD")
         P.emit("v_mov_b32 %s, %s" % (AD, a), writes=[AD])
-        if ctl:
+        while ctl:
             P.emit(ctl.pop(0), salu=True)
         BS = None
         if shifts is None:
@@ -428,9 +451,16 @@ class Gen4(Gen):
         return bl, bh
 
 
+# ---- fetch alignment: tools/asm_grid.py (every 8-byte instruction of a statement starts on an 8-byte boundary) ---------
+ALIGN8 = os.environ.get("ANEMOI_COOP2D_GEN_ALIGN8", "1") == "1"    # (0: A/B builds only)
+
+
 def gen_product(nl, W, kind, rows=2):
     """-> (lines, clobbers, info) of the statement `kind` in KINDS"""
-    return (Gen4 if rows == 4 else Gen)(nl, W, kind).build()
+    lines, clob, info = (Gen4 if rows == 4 else Gen)(nl, W, kind).build()
+    if ALIGN8:
+        lines, info["inserted_for_alignment"] = align8(lines)
+    return lines, clob, info
 
 
 def render(nl, W, rows=2):
@@ -471,7 +501,8 @@ def main():
             h += render(nl, W, rows)
             h.append("};")
     h.append("}  // namespace anemoi")
-    dst = os.path.join(ROOT, "anemoi-rust_amd", "csrc", "coop2d_asm_gen.h" if PAD_DPP_DST else "coop2d_asm_gen_novdst.h")
+    dst = os.path.join(ROOT, "anemoi-rust_amd", "csrc", os.environ.get("ANEMOI_COOP2D_GEN_OUT") or
+                       ("coop2d_asm_gen.h" if PAD_DPP_DST else "coop2d_asm_gen_novdst.h"))
     with open(dst, "w") as f:
         f.write("\n".join(h) + "\n")
     print("wrote", dst)
@@ -479,7 +510,7 @@ def main():
         for rows in ((2, 4) if nl <= 13 else (2,)):
             for kind in KINDS:
                 _, _, info = gen_product(nl, W, kind, rows)
-                print("  %2d limbs of %d bits, %d rows, %-8s %s" % (nl, W, rows, kind, {k: v for k, v in info.items() if k in ("slots", "last_sqr_plus_mul_slots", "nops")}))
+                print("  %2d limbs of %d bits, %d rows, %-8s %s" % (nl, W, rows, kind, {k: v for k, v in info.items() if k in ("slots", "last_sqr_plus_mul_slots", "nops", "inserted_for_alignment")}))
 
 
 if __name__ == "__main__":
