@@ -195,7 +195,7 @@ def run_asm(lines, opnd):
         steps += 1
         assert steps < 100000
         if ln.endswith(":") or ln.startswith("s_nop") or ln.startswith(".p2align") or ln.startswith("v_nop"):
-            continue
+            continue               # (v_nop_e64: the 8-byte stand-in for a lone s_nop 0, tools/asm_grid.py)
         op, _, rest = ln.partition(" ")
         op = re.sub(r"_e(32|64)$", "", op)          # the encoding (4 / 8 bytes) is layout, not semantics
         ctrl = None
@@ -406,7 +406,7 @@ def test_statements_sit_on_the_8_byte_fetch_grid():
     """A lone wavefront pays ~1 cycle for every 8-byte instruction that straddles an 8-byte boundary
     (tools/ubench/lone_wave_fetch.hip), so the generator lays the statements out on an 8-byte grid.  Checked with the
     assembler itself: every line's encoded size is what the generator assumed, and every 8-byte instruction starts at a
-    multiple of 8 from the statement's (aligned) start -- with no padding instruction inserted to get there."""
+    multiple of 8 from the statement's (aligned) start."""
     import shutil
     import subprocess
     mc = shutil.which("llvm-mc") or "/opt/rocm/lib/llvm/bin/llvm-mc"
@@ -415,7 +415,7 @@ def test_statements_sit_on_the_8_byte_fetch_grid():
     for nl, W, rows in [(nl, W, r) for nl, W in G.LAYOUTS for r in ((2, 4) if nl <= 13 else (2,))]:
         for kind in G.KINDS:
             lines, _, info = G.gen_product(nl, W, kind, rows)
-            assert info["inserted_for_alignment"] == 0, (nl, kind)
+            assert info["off_grid"] == 0, (nl, kind)
             assert lines[0] == ".p2align 3"
             cnt = G.operand_names(nl, kind, rows).get("CNT")
             text = []

@@ -4,10 +4,20 @@ A wavefront that has its SIMD to itself pays ~1 cycle extra for every 8-byte ins
 boundary (tools/ubench/lone_wave_fetch.hip, profiles/r04/ubench_lone_wave_fetch.txt: a stream of 8-byte instructions
 costs 4.3 cycles each aligned and 5.3 at offset 4; 4-byte instructions cost the same at any offset).  The generated
 statements are mostly 8-byte instructions (VOP3, DPP, 32-bit literals), so they are laid out on an 8-byte grid: a
-statement starts aligned (.p2align 3), and every run of 4-byte instructions between two 8-byte ones is made even by
-giving one of them its 8-byte encoding (_e64; `s_nop k` becomes two s_nop with the same total wait).  Encodings
-change, issue slots and semantics do not.  tests/test_coop2d_model.py and tests/test_asm_model.py check the result
-against the assembler (llvm-mc): sizes as assumed here, every 8-byte instruction on the grid.
+statement starts aligned (.p2align 3), and the encodings of its 4-byte instructions are chosen -- a VOP1 / VOP2
+instruction may take its 8-byte _e64 form, `s_nop k` may become two s_nop with the same total wait -- so that as few
+8-byte instructions as possible straddle a boundary (a two-state dynamic programme over the text; for every shipped
+statement but the digit-serial scans the minimum is zero).  Encodings change; issue slots and semantics do not.
+
+What is NOT used as padding, and why (same microbenchmark, and the scan kernel at 4 096 / 8 192 items):
+  * an SALU instruction with a literal (8 bytes) in a hazard gap: behind a VALU instruction that writes an SGPR
+    (v_mad_u64_u32 writes vcc) it waits for that write -- +15 cycles per filler;
+  * v_nop_e64 where wavefronts may share a SIMD: it occupies the vector ALU the other wavefront could use (12-23 % on
+    the scan kernel at one / two wavefronts per SIMD); allowed (`vnop=True`) only for the two-row fold statements, which
+    run at <= one wavefront per SIMD, where it costs exactly what the s_nop 0 it replaces costs.
+
+tests/test_coop2d_model.py and tests/test_asm_model.py check the result against the assembler (llvm-mc): sizes as
+assumed here, the 8-byte instructions of every statement on the grid (the scans: at most the count stated there).
 """
 import re
 
@@ -35,32 +45,45 @@ def enc_size(line):
     return 4
 
 
-def align8(lines):
-    """-> (lines on the 8-byte grid, number of padding instructions that had to be INSERTED (each costs an issue slot))"""
-    out, run, off, inserted = [".p2align 3"], [], 0, 0   # run: indices (in out) of the 4-byte instructions since the last 8-byte one
+def _variants(line, vnop):
+    """the ways to write `line` at no cost in issue slots: [(lines, bytes)]"""
+    size = enc_size(line)
+    out = [([line], size)]
+    if size == 4:
+        op, _, rest = line.partition(" ")
+        if op in E32_PROMOTABLE:
+            out.append(([op + "_e64 " + rest], 8))
+        elif op == "s_nop" and int(rest) >= 1:
+            out.append((["s_nop %d" % (int(rest) - 1), "s_nop 0"], 8))
+        elif op == "s_nop" and vnop:
+            out.append((["v_nop_e64"], 8))
+    return out
+
+
+def align8(lines, vnop=False):
+    """-> (the statement on the 8-byte grid, number of 8-byte instructions left straddling a boundary)"""
+    INF = 1 << 30
+    cost = {0: 0, 4: INF}                       # parity of the current offset -> fewest straddlers so far
+    back = []                                   # per line: {parity after: (parity before, variant index)}
     for ln in lines:
-        size = enc_size(ln)
-        if size == 8 and off % 8:
-            for i in reversed(run):
-                op, _, rest = out[i].partition(" ")
-                lit = enc_size(out[i]) == 4
-                if op in E32_PROMOTABLE and lit:
-                    out[i] = op + "_e64 " + rest
-                    break
-                if op == "s_nop" and int(rest) >= 1:
-                    out[i:i + 1] = ["s_nop %d" % (int(rest) - 1), "s_nop 0"]
-                    break
-                if op == "s_nop":
-                    out[i] = "v_nop_e64"
-                    break
-            else:
-                out.append("s_nop 0")
-                inserted += 1
-            off += 4
-        out.append(ln)
-        off += size
-        if size == 8:
-            run = []
-        elif size == 4:
-            run.append(len(out) - 1)
-    return out, inserted
+        new, step = {0: INF, 4: INF}, {}
+        for p in (0, 4):
+            if cost[p] >= INF:
+                continue
+            for vi, (_, size) in enumerate(_variants(ln, vnop)):
+                q = (p + size) % 8
+                c = cost[p] + (1 if size == 8 and p else 0)
+                if c < new[q]:
+                    new[q], step[q] = c, (p, vi)
+        cost = new
+        back.append(step)
+    p = min(cost, key=cost.get)
+    total = cost[p]
+    chosen = []
+    for ln, step in zip(reversed(lines), reversed(back)):
+        p, vi = step[p]
+        chosen.append(_variants(ln, vnop)[vi][0])
+    out = [".p2align 3"]
+    for c in reversed(chosen):
+        out += c
+    return out, total

@@ -26,11 +26,16 @@ statement (NL + 1 s_mov_b32).  Temporaries live in fixed clobbered VGPRs v[TMP_B
 """
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELD_IDS = ["bls12_381", "bls12_377", "bn_254", "ed_on_bls12_377", "jubjub", "pallas", "vesta"]
 TMP_BASE = int(os.environ.get("ANEMOI_ASM_TMP_BASE", "100"))  # clobbered VGPRs start here (even: the 64-bit accumulator is 2-aligned)
 TMP_BASE9 = int(os.environ.get("ANEMOI_ASM_TMP_BASE9", str(TMP_BASE)))  # the same for the 9-limb fields (A/B of their occupancy)
+
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from asm_grid import align8  # noqa: E402  (the 8-byte fetch grid: see tools/asm_grid.py)
 
 
 def tmp_base(nl):
@@ -242,9 +247,10 @@ def gen_mul(nl, plimbs, n0inv, W, p=None):
     SP = lambda i: "s%d" % (SGPR_BASE + i)
     SN0 = "s%d" % (SGPR_BASE + nl)
     out = []
-    for i in range(nl):
-        out.append("s_mov_b32 %s, 0x%x" % (SP(i), plimbs[i]))
-    out.append("s_mov_b32 %s, 0x%x" % (SN0, n0inv))
+    consts = [(SP(i), plimbs[i]) for i in range(nl)] + [(SN0, n0inv)]
+    # (those with a 32-bit literal first, the 4-byte inline-constant forms together behind them: the 8-byte fetch grid)
+    for dst, v in sorted(consts, key=lambda c: c[1] <= 64):
+        out.append("s_mov_b32 %s, 0x%x" % (dst, v))
     xacc = [((treg + 2 + 1) & ~1) + 2 * i for i in range(CHAINS - 1)]
     col = Column(out, W, acc, treg, cz, xacc)
     for k in range(2 * nl - 1):
@@ -333,9 +339,10 @@ def gen_coop4_mul(nl, n0inv, W=29):
     (W in lane j = 0 of each row, 63 elsewhere), %6 = MASK (a VGPR: src1 of a VOP2).  Per step i:
         T += a_i * b
         x  = T.lo * n0inv                    (v_sub_u32 x, 0, T.lo when p = 1 mod 2^W)
-        m  = bcast_row(x, 0) & MASK          the next a_i is broadcast in the wait states in front of this DPP read
+        m  = bcast_row(x, 0) & MASK          (two wait states in front of this DPP read)
         T += m * p_lane
         U  = T >> shift                      lane 0 of a row: the retired column's carry; other lanes: 0 (T < 2^63)
+                                             (the next a_i is broadcast in the wait state behind the shift)
         T  = T_{lane+1} + U                  v_add_co_u32 / v_addc_co_u32 with DPP row_shl:1 on src0
     10 issue slots per step like the one-element scan (whose quotient digit runs on the scalar ALU).  Hazard slots
     by hand: VALU-written VGPR -> DPP source needs 2 wait states."""
@@ -356,15 +363,14 @@ def gen_coop4_mul(nl, n0inv, W=29):
             out.append("v_sub_u32 v%d, 0, v%d" % (X, T))
         else:
             out.append("v_mul_lo_u32 v%d, v%d, %s" % (X, T, SN))
-        if i + 1 < nl:
-            out.append("v_mov_b32_dpp %s, %%2 %s" % (A(i + 1), bc(i + 1)))   # fills one of the two wait states
-            out.append("s_nop 0")
-        else:
-            out.append("s_nop 1")
+        out.append("s_nop 1")       # (two wait states as ONE instruction: tools/asm_grid.py may write it as two s_nop 0 = 8 bytes)
         out.append("v_and_b32_dpp v%d, v%d, %%6 %s" % (M, X, bc(0)))
         out.append("v_mad_u64_u32 %s, vcc, v%d, %%4, %s" % (TT, M, TT))
         out.append("v_lshrrev_b64 %s, %%5, %s" % (UU, TT))
-        out.append("s_nop 0")
+        if i + 1 < nl:
+            out.append("v_mov_b32_dpp %s, %%2 %s" % (A(i + 1), bc(i + 1)))   # the next a_i fills the wait state (8 bytes: the
+        else:                                                                 # step stays on the 8-byte fetch grid)
+            out.append("v_mov_b32_dpp %s, %%2 %s" % (A(i + 1), bc(0)))       # (last step: a broadcast nobody reads, for the same 8 bytes)
         out.append("v_add_co_u32_dpp v%d, vcc, v%d, v%d %s" % (T, T, U, shl))
         out.append("v_addc_co_u32_dpp v%d, vcc, v%d, v%d, vcc %s" % (T + 1, T + 1, U + 1, shl))
     out.append("v_mov_b32 %%0, v%d" % T)
@@ -459,6 +465,8 @@ def main():
             nl, pl, n0 = field_consts(p, W)
             sq, sq_clob, sq_splits, sq_light = gen_sqr(nl, pl, n0, W, p)
             mu, mu_clob, mu_splits, mu_light = gen_mul(nl, pl, n0, W, p)
+            (sq, sq_pad), (mu, mu_pad) = align8(sq), align8(mu)
+            assert sq_pad + mu_pad == 0, (name, W, sq_pad, mu_pad)   # (8-byte instructions left off the grid)
             nmad = sum(1 for l in sq if l.startswith("v_mad"))
             tag = "%d_%d" % (fid, W)
             h.append("// %s, %d-bit limbs: %d limbs; squaring %d instructions (%d v_mad_u64_u32, %d split columns), "
@@ -506,7 +514,8 @@ def main():
         p = int(params[name]["modulus"])
         nl, pl, n0 = field_consts(p, 29)
         co, co_clob = gen_coop_mul(nl, n0)
-        h.append("// %s: %d steps, %d instructions" % (name, nl, len(co)))
+        co, off_grid = align8(co)
+        h.append("// %s: %d steps, %d instructions (%d of the 8-byte ones off the fetch grid)" % (name, nl, len(co), off_grid))
         h.append("template <> struct AsmCoop<%d> {" % fid)
         h.append("  __device__ static __forceinline__ uint64_t mul(uint32_t a, uint32_t b, uint32_t pl, uint32_t sh) {")
         h.append("    uint32_t lo, hi;")
@@ -520,7 +529,8 @@ def main():
         p = int(params[name]["modulus"])
         nl, pl, n0 = field_consts(p, 29)
         co, co_clob = gen_coop4_mul(nl, n0)
-        h.append("// %s: %d steps, %d instructions" % (name, nl, len(co)))
+        co, off_grid = align8(co)
+        h.append("// %s: %d steps, %d instructions (%d of the 8-byte ones off the fetch grid)" % (name, nl, len(co), off_grid))
         h.append("template <> struct AsmCoop4<%d> {" % fid)
         h.append("  __device__ static __forceinline__ uint64_t mul(uint32_t a, uint32_t b, uint32_t pl, uint32_t sh, uint32_t mask) {")
         h.append("    uint32_t lo, hi;")
@@ -539,6 +549,7 @@ def main():
         p = int(params[name]["modulus"])
         Mt, Mq, n = coop_qp_params(p)
         co, co_clob = gen_coop_mul_qp(n)
+        co, off_grid = align8(co)
         h.append("// %s: %d limbs / steps, %d instructions" % (name, n, len(co)))
         h.append("template <> struct AsmCoopQP<%d> {" % fid)
         h.append("  static constexpr int NX = %d;" % n)

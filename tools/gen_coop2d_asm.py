@@ -459,7 +459,7 @@ def gen_product(nl, W, kind, rows=2):
     """-> (lines, clobbers, info) of the statement `kind` in KINDS"""
     lines, clob, info = (Gen4 if rows == 4 else Gen)(nl, W, kind).build()
     if ALIGN8:
-        lines, info["inserted_for_alignment"] = align8(lines)
+        lines, info["off_grid"] = align8(lines, vnop=True)   # (<= one wavefront per SIMD: v_nop_e64 may stand in for s_nop 0)
     return lines, clob, info
 
 
@@ -510,7 +510,7 @@ def main():
         for rows in ((2, 4) if nl <= 13 else (2,)):
             for kind in KINDS:
                 _, _, info = gen_product(nl, W, kind, rows)
-                print("  %2d limbs of %d bits, %d rows, %-8s %s" % (nl, W, rows, kind, {k: v for k, v in info.items() if k in ("slots", "last_sqr_plus_mul_slots", "nops", "inserted_for_alignment")}))
+                print("  %2d limbs of %d bits, %d rows, %-8s %s" % (nl, W, rows, kind, {k: v for k, v in info.items() if k in ("slots", "last_sqr_plus_mul_slots", "nops", "off_grid")}))
 
 
 if __name__ == "__main__":

@@ -86,6 +86,30 @@ TIMED(k_add_2_swap, ".rept 64\n\t" ADD32(0) ADD32(2) ADD32(3) "v_permlane16_swap
 // mad whose 64-bit result is read by the next instruction's 32-bit halves
 TIMED(k_mad_use, ".rept 128\n\t" MAD(8) "v_lshl_add_u64 %9, %8, 0, %9\n\t" ".endr\n\t", 256)
 
+#define VNOP64(i) "v_nop_e64\n\t"
+#define VNOP32(i) "v_nop\n\t"
+#define SUB64(i) "v_sub_u32_e64 %" #i ", 0, %" #i "\n\t"
+TIMED(k_vnop64, X32(R8(VNOP64)), 256)
+TIMED(k_vnop32, X32(R8(VNOP32)), 256)
+TIMED(k_sub64, X32(R8(SUB64)), 256)
+// the scan step's gap: a write, one independent instruction, a filler, the DPP read of the write -- filler = s_nop 0 / v_nop_e64
+TIMED(k_gap_snop, ".rept 32\n\t" ADD64(0) MAD(8) "s_nop 0\n\ts_nop 0\n\t" "v_add_u32_dpp %3, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" MAD(9) MAD(10) MAD(11) ".endr\n\t", 256)
+TIMED(k_gap_vnop, ".rept 32\n\t" ADD64(0) MAD(8) "v_nop_e64\n\t" "v_add_u32_dpp %3, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" MAD(9) MAD(10) MAD(11) ".endr\n\t", 224)
+
+// VALU and SALU / s_nop interleaved one to one
+#define VS_SADD(i) "v_add_u32_e64 %" #i ", %13, %" #i "\n\ts_add_u32 s91, s91, 1\n\ts_nop 0\n\t"
+#define VS_SMOVLIT(i) "v_add_u32_e64 %" #i ", %13, %" #i "\n\ts_mov_b32 s91, 0x7fffffff\n\t"
+#define VS_SNOP(i) "v_add_u32_e64 %" #i ", %13, %" #i "\n\ts_nop 0\n\ts_nop 0\n\t"
+#define VS_SCMP(i) "v_add_u32_e64 %" #i ", %13, %" #i "\n\ts_cmp_eq_u32 s91, 0\n\ts_nop 0\n\t"
+TIMED(k_vs_sadd, ".rept 16\n\t" R8(VS_SADD) ".endr\n\t", 384)
+TIMED(k_vs_smovlit, ".rept 16\n\t" R8(VS_SMOVLIT) ".endr\n\t", 256)
+TIMED(k_vs_snop, ".rept 16\n\t" R8(VS_SNOP) ".endr\n\t", 384)
+TIMED(k_vs_scmp, ".rept 16\n\t" R8(VS_SCMP) ".endr\n\t", 384)
+// the scan step's filler between a VALU write and the DPP read two slots later
+#define GAP(F) ".rept 32\n\t" ADD64(0) MAD(8) F "v_add_u32_dpp %3, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" MAD(9) MAD(10) MAD(11) ".endr\n\t"
+TIMED(k_gap_smov, GAP("s_mov_b32 s91, 0x7fffffff\n\t"), 224)
+TIMED(k_gap_snop0, GAP("s_nop 0\n\t"), 224)
+
 // taken branches: K e32 adds (4 B each), then an unconditional branch to the next group; target aligned to 64 B,
 // or deliberately 4 B before a 64 B boundary
 #define GROUP_ALIGNED(K) ".rept 16\n\t.p2align 6\n\t.rept " #K "\n\tv_add_u32_e32 %0, %13, %0\n\t.endr\n\ts_branch 1f\n\t.p2align 6\n\t1:\n\t.endr\n\t"
@@ -119,6 +143,11 @@ int main() {
                   {"mad, add, add, dpp(of older reg)", k_mad_then_dpp}, {"add a, add, add, dpp reads a", k_add_2_dpp},
                   {"add a, s_nop 1, dpp reads a, add", k_add_nop_dpp}, {"add a, add, add, swap16 a", k_add_2_swap},
                   {"mad, 64-bit add of its result", k_mad_use},
+                  {"v_nop_e64 (8 B)", k_vnop64}, {"v_nop (4 B)", k_vnop32}, {"v_sub_u32_e64 (8 B)", k_sub64},
+                  {"add a, mad, s_nop 0 x2, dpp reads a, 3 mads", k_gap_snop}, {"add a, mad, v_nop_e64, dpp reads a, 3 mads", k_gap_vnop},
+                  {"(v_add, s_add, s_nop 0) x", k_vs_sadd}, {"(v_add, s_mov literal) x", k_vs_smovlit},
+                  {"(v_add, s_nop 0, s_nop 0) x", k_vs_snop}, {"(v_add, s_cmp, s_nop 0) x", k_vs_scmp},
+                  {"add a, mad, s_mov literal, dpp reads a, 3 mads", k_gap_smov}, {"add a, mad, s_nop 0, dpp reads a, 3 mads", k_gap_snop0},
                   {"8 adds + taken branch, aligned", k_br_a8}, {"32 adds + taken branch, aligned", k_br_a32},
                   {"8 adds + taken branch, target at line end", k_br_u8}, {"32 adds + taken, target at line end", k_br_u32},
                   {"8 adds + cmp + not-taken branch", k_nt8},
