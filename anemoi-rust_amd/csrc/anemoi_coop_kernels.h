@@ -47,9 +47,9 @@ struct CoopArith<F, 64, true> { using type = Coop2d<F, 4>; };
 // through anemoi_set_option; the parity tests force each kernel for every size that way).
 // One item per wavefront (k_jive2_coop<F, 64>): NEVER by default -- A/B and parity only.  On the 11-limb fields this is
 // the FOUR-row fold product (an element on all four rows: half the multiply-adds per wavefront, 67 instructions per
-// squaring instead of 73), which measures SLOWER than the two-row form (Jubjub 1.145 vs 1.073 ms per compression,
+// squaring instead of 73), which measures SLOWER than the two-row form (Jubjub 1.073 vs 0.960 ms per compression,
 // profiles/r04/coop_kernel_sweep.txt): its two extra swap levels and three-row form builds leave 18 hazard slots per
-// product that nothing can fill (85 issue slots against 79), and a lone wavefront pays for every slot.  On the 15-limb
+// product that nothing can fill (86 issue slots against 79), and a lone wavefront pays for every slot.  On the 15-limb
 // fields it is rounds 1-2's one-element scan kernel.
 inline size_t coop_max_items() { return size_t(opt::get_or(opt::kCoopMax, 0)); }
 // Anemoi-2-1 batches up to this size take the two-row fold kernels (coop2d.h, two items per wavefront): one

@@ -3,8 +3,9 @@
 // Merkle tree, a single Jive::compress / Sponge::merge / hash through the shim).
 //
 // coop29.h's product is a digit-serial scan: NL steps of ten issue slots, each waiting for the quotient digit of the
-// step before.  A lone wavefront issues one instruction per ~4.7 cycles whatever the dependences, so the latency of a
-// compression is the INSTRUCTION COUNT of its ~6 500 / ~10 000 sequential products.  This layout spreads a product
+// step before.  A wavefront alone on its SIMD issues one instruction -- or one wait slot -- per 4.08 cycles whatever the
+// dependences (tools/ubench/lone_wave_fetch.hip), so the latency of a compression is the ISSUE-SLOT COUNT of its ~6 500 /
+// ~10 000 sequential products (plus what their layout costs: DESIGN 3.5b).  This layout spreads a product
 // over two rows and removes the quotient digits altogether (tools/coop2d_model.py is the executable specification):
 //
 //   layout   NL limbs of W = 28 bits, limb j in lane j of BOTH rows of the pair (lanes >= NL hold zero), Montgomery
@@ -49,8 +50,8 @@ namespace anemoi {
 // ROWS = 2: an element on a row pair, two per wavefront.  ROWS = 4 (11-limb fields): an element on all four rows, ONE
 // per wavefront -- row r multiplies by the limbs a_i, i = r (mod 4), so a phase takes ceil(NL / 4) steps: half the
 // multiply-adds, broadcasts and shifts per wavefront for a second swap level (v_permlane32_swap) in the sums over the
-// rows.  Built, bit-exact, and MEASURED SLOWER than two rows (18 unfillable hazard slots per product against 6: 85 issue
-// slots against 79; Jubjub 1.145 vs 1.073 ms): kept selectable (option coop_max) as the recorded negative, not routed to.
+// rows.  Built, bit-exact, and MEASURED SLOWER than two rows (18 unfillable hazard slots per product against 6: 86 issue
+// slots against 79; Jubjub 1.073 vs 0.960 ms): kept selectable (option coop_max) as the recorded negative, not routed to.
 template <class F, int ROWS = 2>
 struct Coop2d {
   using L = typename F::Fold;

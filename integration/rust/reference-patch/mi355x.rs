@@ -16,7 +16,7 @@
 //
 // SMALL-BATCH POLICY (one rule for every function): fewer than MI355X_MIN_BATCH items stay on the CPU,
 // item by item through the unchanged trait functions; MI355X_MIN_BATCH or more go to the GPU.  A single
-// Jive::compress costs 1.83 ms (BLS12-381) / 1.07 ms (Jubjub) on the GPU's latency kernel against ~0.43 ms /
+// Jive::compress costs 1.71 ms (BLS12-381) / 0.96 ms (Jubjub) on the GPU's latency kernel against ~0.43 ms /
 // ~0.13 ms on one CPU core (profiles/r04/reference_criterion_workloads.txt, reference README.md:77-78), so
 // the GPU only pays from a few tens of items up; 32 is past break-even for all 14 instances.
 // `Jive::compress` / `Sponge::hash` themselves (batches of one) are therefore NOT rerouted.

@@ -9,7 +9,8 @@ assembly.  Three statements per layout:
                            lane shifts, which do not depend on the squarings) is issued in the hazard gaps of the LAST
                            squaring
 
-Why: a lone wavefront issues one instruction (or s_nop) per ~4.7 cycles, so a product costs its issue slots.  hipcc's
+Why: a wavefront alone on its SIMD issues one instruction (or s_nop slot) per 4.08 cycles whatever the dependences
+(tools/ubench/lone_wave_fetch.hip), so a product costs its issue slots.  hipcc's
 version of Coop2d::mul is 94 slots per squaring on 11 limbs: 76 instructions + 18 hazard s_nop (it re-uses a handful of
 registers, so nearly every DPP / permlane read waits for the write before it).  Scheduled by hand the hazard slots are
 filled with work that is there anyway -- the HI multiply-adds of P1 are issued inside the carry chain of RN1, loop
