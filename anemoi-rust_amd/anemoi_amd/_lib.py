@@ -145,7 +145,7 @@ def release(device=ALL_DEVICES):
         raise AnemoiError(rc, lib.anemoi_last_error().decode())
 
 
-OPTIONS = ("coop_max", "coop2d_max", "coop4_max", "coop43_max", "coop_sponge_max", "coop_climb_max",
+OPTIONS = ("coop_max", "coop2d_max", "coop4_max", "coop43_max", "coop2d43_max", "coop_sponge_max", "coop_climb_max",
            "virtual_devices", "host_staging", "chunk_target_bytes", "test_quantum",
            "sponge_segment_bytes")
 AUTO = -1

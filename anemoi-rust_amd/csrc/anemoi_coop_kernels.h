@@ -62,6 +62,9 @@ inline size_t coop4_max_items(int simds) { return size_t(opt::get_or(opt::kCoop4
 inline size_t coop43_max_items(int simds, int limbs29) {
   return size_t(opt::get_or(opt::kCoop43Max, (limbs29 >= 14 ? 4ll : 2ll) * simds));
 }
+// Anemoi-4-3 batches (Jive, permutation, equal-length sponge) up to this many states take the two-row fold kernels with
+// ONE state per wavefront (a column per row pair): one wavefront per SIMD
+inline size_t coop2d43_max_items(int simds) { return size_t(opt::get_or(opt::kCoop2d43Max, 1ll * simds)); }
 // Sponge batches (whole messages of one length in one launch) of up to this many messages take k_sponge_coop
 // (1 KB messages: Jubjub 2-1 49.1 vs 86.5 ms up to 1 024 messages, 51.6 vs 86.7 at 4 096, 134.6 vs 86.8 at 16 384;
 // BN-254 4-3 12.0 vs 22.4 ms, 18.3 vs 22.4 at 4 096, 61.8 vs 22.9 at 16 384)
@@ -205,8 +208,8 @@ struct CoopArk<Coop2d<F, ROWS>> {
 
 // Anemoi::permutation (src/traits.rs:370-378) on the cooperative arithmetic, for one column (x, y) per element row.
 //   W = 2: the state is (x, y); mds_layer arm NUM_COLUMNS = 1 (src/traits.rs:136-142).
-//   W = 4: a state's two columns sit on two adjacent 16-lane rows (row 2s holds (x0, y0) = (state[0], state[2]),
-//          row 2s + 1 holds (x1, y1)) -- the lane-pair idea of anemoi_perm.h one level up.  The two S-boxes of a
+//   W = 4: a state's two columns sit on two adjacent 16-lane rows -- or, on the two-row fold arithmetic, on the two row
+//          pairs of the wavefront -- (column 0 holds (x0, y0) = (state[0], state[2]), column 1 holds (x1, y1)) -- the lane-pair idea of anemoi_perm.h one level up.  The two S-boxes of a
 //          round run side by side; only the linear layer (arm 2, src/traits.rs:143-157) couples the rows, through
 //          five cross-row exchanges per round.  Every cross-lane operation (the row exchange, the DPP carries
 //          inside add / mul_g) is executed by ALL lanes and the result selected afterwards: under divergent control
@@ -215,9 +218,10 @@ template <class F, class C, int W>
 __device__ __forceinline__ void coop_permutation(uint32_t& x, uint32_t& y, const typename C::K& k, uint32_t* tab,
                                                  const PermConsts& pc) {
   constexpr int NL = C::NL, R = W == 2 ? F::kRounds21 : F::kRounds43;
-  const uint32_t j = C::limb(), col = W == 4 ? ((threadIdx.x / 16) & 1) : 0;
+  constexpr int LPI = C::kLanesPerItem;      // lanes of one column: a 16-lane row (scan) or a row pair (two-row fold)
+  const uint32_t j = C::limb(), col = W == 4 ? ((threadIdx.x / LPI) & 1) : 0;
   const bool odd = col != 0;
-  auto other = [](uint32_t v) { return (uint32_t)__shfl_xor((int)v, 16); };   // the same limb of the partner row
+  auto other = [](uint32_t v) { return (uint32_t)__shfl_xor((int)v, LPI); };   // the same limb of the partner column
   // round constants: the NEXT round's pair is fetched while this round's S-box runs (vector loads, one limb per lane)
   auto konst = [&](const uint32_t* tabk, int r) { return j < NL ? tabk[(r * (W / 2) + int(col)) * NL + j] : 0u; };
   const uint32_t* const ark_c = CoopArk<C>::c(pc);
@@ -237,13 +241,13 @@ __device__ __forceinline__ void coop_permutation(uint32_t& x, uint32_t& y, const
       // s0 += g s1 ; s1 += g s0 ; s3 += g s2 ; s2 += g s3 ; swap(s2, s3) ; s2 += s0 ; s3 += s1 ; s0 += s2 ; s1 += s3
       uint32_t ox = other(x), oy = other(y);
       uint32_t p = odd ? oy : ox;               // even: s1 (the odd row's x); odd: s2 (the even row's y)
-      uint32_t t = C::mul_g(p, k);
+      uint32_t t = C::mul_g_settled(p, k);      // (a product: the fold arithmetic's values are not tight enough to scale)
       uint32_t sx = C::add(x, t), sy = C::add(y, t);
       x = odd ? x : sx;                         // even: s0 += g s1
       y = odd ? sy : y;                         // odd:  s3 += g s2
       ox = other(x), oy = other(y);
       p = odd ? ox : oy;                        // odd: the updated s0; even: the updated s3
-      t = C::mul_g(p, k);
+      t = C::mul_g_settled(p, k);
       sx = C::add(x, t), sy = C::add(y, t);
       x = odd ? sx : x;                         // odd:  s1 += g s0
       y = odd ? y : sy;                         // even: s2 += g s3
@@ -287,14 +291,16 @@ __global__ __launch_bounds__(kBlock) void k_jive2_coop(const uint32_t* __restric
 // Anemoi-4-3 Jive on the row-cooperative arithmetic: TWO states per wavefront (coop_permutation<.., 4>).
 // K = 2: out[i] = e_i + e_{i+2} + s_i + s_{i+2} is row-local; K = 4: the two rows' sums are added
 // (anemoi_4_3/hasher.rs:148-179).
-template <int FIELD, int K>
+// LPR = 32: ONE state per wavefront on the two-row fold arithmetic, a column per row pair -- the lowest latency.
+template <int FIELD, int K, int LPR = 16>
 __global__ __launch_bounds__(kBlock) void k_jive4_coop(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                        size_t n, PermConsts pc) {
   using F = FieldC<FIELD>;
-  using C = Coop29<F, 16>;
-  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = 2;
+  using C = typename CoopArith<F, LPR>::type;
+  static_assert(LPR == 16 || LPR == 32, "a column per 16-lane row, or per row pair");
+  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = kBlock / (2 * LPR);
   __shared__ uint32_t tab[E * kBlock];
-  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / 16, col = row & 1;
+  const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR, col = row & 1;
   const bool odd = col != 0;
   const typename C::K k = C::load_consts();
   const size_t groups = (n + PER - 1) / PER;
@@ -308,13 +314,13 @@ __global__ __launch_bounds__(kBlock) void k_jive4_coop(const uint32_t* __restric
     uint32_t x = e0, y = e1;
     coop_permutation<F, C, 4>(x, y, k, tab, pc);
     uint32_t s = C::add(C::add(x, y), C::add(e0, e1));   // this column's share of the Jive sum
-    const uint32_t os = (uint32_t)__shfl_xor((int)s, 16);
+    const uint32_t os = (uint32_t)__shfl_xor((int)s, LPR);
     if (K == 4) s = C::add(s, os);
     const uint32_t o = C::to_abi(s, k);
     if (K == 2) {
-      if (live && j < NABI) out[(item * 2 + col) * NABI + j] = o;
+      if (live && C::writer() && j < NABI) out[(item * 2 + col) * NABI + j] = o;
     } else {
-      if (live && !odd && j < NABI) out[item * NABI + j] = o;
+      if (live && !odd && C::writer() && j < NABI) out[item * NABI + j] = o;
     }
   }
 }
@@ -325,8 +331,8 @@ template <int FIELD, int W, int LPR = 16>
 __global__ __launch_bounds__(kBlock) void k_permutation_coop(uint32_t* __restrict__ states, size_t n, PermConsts pc) {
   using F = FieldC<FIELD>;
   using C = typename CoopArith<F, LPR>::type;
-  static_assert(LPR == 16 || W == 2, "the 4-3 form puts a state's two columns on two adjacent 16-lane rows");
-  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? kBlock / LPR : 2;
+  static_assert(LPR <= 32 || W == 2, "the 4-3 form puts a state's two columns on two adjacent rows / row pairs");
+  constexpr int NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? kBlock / LPR : kBlock / (2 * LPR);
   __shared__ uint32_t tab[E * kBlock];
   const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR, col = W == 4 ? (row & 1) : 0;
   const typename C::K k = C::load_consts();
@@ -393,8 +399,9 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
                                                         uint32_t* __restrict__ out, PermConsts pc) {
   using F = FieldC<FIELD>;
   using C = typename CoopArith<F, LPR>::type;
-  static_assert(LPR == 16 || W == 2, "the 4-3 form puts a state's two columns on two adjacent 16-lane rows");
-  constexpr int NL = C::NL, NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? kBlock / LPR : 2, RATE = W - 1;
+  static_assert(LPR <= 32 || W == 2, "the 4-3 form puts a state's two columns on two adjacent rows / row pairs");
+  constexpr int NL = C::NL, NABI = C::NABI, E = 1 << (F::kCoopWin - 1), PER = W == 2 ? kBlock / LPR : kBlock / (2 * LPR),
+                RATE = W - 1;
   __shared__ uint32_t tab[E * kBlock];
   const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR, col = W == 4 ? (row & 1) : 0;
   const bool odd = col != 0;

@@ -638,7 +638,7 @@ namespace anemoi {
 struct HostConsts {  // what the context uploads for one (field, width)
   std::vector<uint32_t> ark_c, ark_d;    // lane-private limb layout (F::Lane)
   std::vector<uint32_t> coop_c, coop_d;  // the instance's round constants in the cooperative kernels' layout (F::Coop)
-  std::vector<uint32_t> fold_c, fold_d;  // ... and in the two-row fold layout (F::Fold; width 2 only)
+  std::vector<uint32_t> fold_c, fold_d;  // ... and in the two-row fold layout (F::Fold)
   std::vector<uint8_t> sched, sched5, sched_plain;
   int steps, first, steps5, first5, steps_plain, first_plain;
 };
@@ -704,6 +704,8 @@ struct Launch {
     } else {
       hc->coop_c.assign(CL::ArkC_43, CL::ArkC_43 + 2 * F::kRounds43 * CL::NL);
       hc->coop_d.assign(CL::ArkD_43, CL::ArkD_43 + 2 * F::kRounds43 * CL::NL);
+      hc->fold_c.assign(FL::ArkC_43, FL::ArkC_43 + 2 * F::kRounds43 * FL::NL);
+      hc->fold_d.assign(FL::ArkD_43, FL::ArkD_43 + 2 * F::kRounds43 * FL::NL);
     }
     static_assert(WIN >= 2 && WIN <= 5, "schedules are generated for 2..5-bit windows");
     static_assert(F::kCoopWin >= 2 && F::kCoopWin <= 5, "");
@@ -743,9 +745,13 @@ struct Launch {
   static hipError_t permutation(int width, int sbox_only, void* d, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
     // latency path: the cut-offs of the Jive kernels (same permutation, same items per wavefront)
-    if (!sbox_only && width == 2 && n <= coop2d_max_items(pc.simds)) {
+    if (!sbox_only && width == 2 && pc.fold_c && n <= coop2d_max_items(pc.simds)) {
       const size_t groups = (n + 1) / 2;
       k_permutation_coop<FIELD, 2, 32><<<unsigned(groups < 65536 ? groups : 65536), kBlock, 0, s>>>((uint32_t*)d, n, pc);
+      return hipGetLastError();
+    }
+    if (!sbox_only && width == 4 && pc.fold_c && n <= coop2d43_max_items(pc.simds)) {   // one 4-3 state per wavefront, a column per row pair
+      k_permutation_coop<FIELD, 4, 32><<<unsigned(n < 65536 ? n : 65536), kBlock, 0, s>>>((uint32_t*)d, n, pc);
       return hipGetLastError();
     }
     if (!sbox_only && n <= (width == 2 ? coop4_max_items(pc.simds) : coop43_max_items(pc.simds, F::Coop::NL))) {
@@ -773,7 +779,7 @@ struct Launch {
       k_jive2_coop<FIELD, 64><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
-    if (width == 2 && n <= coop2d_max_items(pc.simds)) {  // two items per wavefront on row pairs: the lowest latency
+    if (width == 2 && pc.fold_c && n <= coop2d_max_items(pc.simds)) {  // two items per wavefront on row pairs: the lowest latency
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       k_jive2_coop<FIELD, 32><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
@@ -783,6 +789,12 @@ struct Launch {
       const size_t groups = (n + 3) / 4;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       k_jive2_coop<FIELD, 16><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
+      return hipGetLastError();
+    }
+    if (width == 4 && pc.fold_c && n <= coop2d43_max_items(pc.simds)) {  // 4-3, lowest latency: one state per wavefront on the two-row fold
+      const unsigned g = n < 65536 ? unsigned(n) : 65536u;
+      if (k == 2) k_jive4_coop<FIELD, 2, 32><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
+      else k_jive4_coop<FIELD, 4, 32><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
     if (width == 4 && n <= coop43_max_items(pc.simds, F::Coop::NL)) {  // 4-3 latency path: two states per wavefront
@@ -804,11 +816,17 @@ struct Launch {
   static hipError_t sponge_seg(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
                                SpongeSeg seg, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (seg.first && seg.last && width == 2 && n <= coop2d_max_items(pc.simds)) {  // two messages per wavefront
+    if (seg.first && seg.last && width == 2 && pc.fold_c && n <= coop2d_max_items(pc.simds)) {  // two messages per wavefront
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       if (bytes) k_sponge_coop<FIELD, 2, true, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
       else k_sponge_coop<FIELD, 2, false, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
+      return hipGetLastError();
+    }
+    if (seg.first && seg.last && width == 4 && pc.fold_c && n <= coop2d43_max_items(pc.simds)) {  // one 4-3 message per wavefront
+      const unsigned g = n < 65536 ? unsigned(n) : 65536u;
+      if (bytes) k_sponge_coop<FIELD, 4, true, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
+      else k_sponge_coop<FIELD, 4, false, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
       return hipGetLastError();
     }
     if (seg.first && seg.last && n <= coop_sponge_max_items(pc.simds)) {  // latency path: whole small batches
@@ -858,7 +876,7 @@ struct Launch {
   static hipError_t merkle_climb(const void* leaves, const void* index, const void* paths, unsigned depth, size_t n,
                                  void* out, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (n <= coop2d_max_items(pc.simds)) {  // very few paths: two per wavefront on row pairs
+    if (pc.fold_c && n <= coop2d_max_items(pc.simds)) {  // very few paths: two per wavefront on row pairs
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       k_merkle_climb_coop<FIELD, 32><<<g, kBlock, 0, s>>>((const uint32_t*)leaves, (const uint64_t*)index,

@@ -160,6 +160,8 @@ struct Coop29 {
     return settle_columns((uint64_t)x * (uint32_t)F::kG);
   }
 
+  __device__ static __forceinline__ uint32_t mul_g_settled(uint32_t x, const K& k) { return mul_g(x, k); }   // (coop2d.h's name)
+
   __device__ static __forceinline__ uint32_t settle(uint32_t x, const K& k) { return mul(x, k.one, k.pl); }
 
   // x < 2p -> x mod p, exact limbs

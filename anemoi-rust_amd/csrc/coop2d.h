@@ -352,6 +352,9 @@ struct Coop2d {
     else return mul(x, k.gm, k);
   }
 
+  // g * x as a PRODUCT (the result is as small as any product's): the 4-3 linear layer, whose sums would not stay below R'
+  __device__ static __forceinline__ uint32_t mul_g_settled(uint32_t x, const K& k) { return mul(x, k.gm, k); }
+
   // x < 2p -> x mod p, exact limbs (borrow look-ahead, as coop29.h)
   __device__ static __forceinline__ uint32_t canonical(uint32_t x, uint32_t pl) {
     x = norm_exact(x);

@@ -24,6 +24,7 @@ enum Id {
   kCoop2dMax,           // largest batch (Jive 2-1, permutation 2-1, sponge 2-1, path climb) on the two-row 2-D kernels
   kCoop4Max,            // largest Jive 2-1 / permutation batch on the row-cooperative kernel (four items per wavefront)
   kCoop43Max,           // largest Jive 4-3 / permutation batch on the row-cooperative 4-3 kernel (two states per wavefront)
+  kCoop2d43Max,         // largest 4-3 batch (Jive, permutation, sponge) on the two-row fold kernels (one state per wavefront)
   kCoopSpongeMax,       // largest equal-length sponge batch on k_sponge_coop
   kCoopClimbMax,        // largest batch of authentication paths on k_merkle_climb_coop
   kTestQuantum,         // items per "full wave of workgroups" of the chunked host pipelines (auto: occupancy API)
@@ -46,6 +47,7 @@ inline const Spec& spec(int id) {
       {"coop2d_max", "ANEMOI_COOP2D_MAX", 0, 1ll << 62},
       {"coop4_max", "ANEMOI_COOP4_MAX", 0, 1ll << 62},
       {"coop43_max", "ANEMOI_COOP43_MAX", 0, 1ll << 62},
+      {"coop2d43_max", "ANEMOI_COOP2D43_MAX", 0, 1ll << 62},
       {"coop_sponge_max", "ANEMOI_COOP_SPONGE_MAX", 0, 1ll << 62},
       {"coop_climb_max", "ANEMOI_COOP_CLIMB_MAX", 0, 1ll << 62},
       {"test_quantum", "ANEMOI_TEST_QUANTUM", 1, 1ll << 40},

@@ -109,6 +109,9 @@ int anemoi_release(int device);
  *                                                                                      kernel (four items per wavefront); above: lane-private
  *   coop43_max             ANEMOI_COOP43_MAX            2 x SIMDs (4-limb fields),     the same for Anemoi-4-3 (two states per wavefront)
  *                                                       4 x SIMDs (6-limb)
+ *   coop2d43_max           ANEMOI_COOP2D43_MAX          1 x SIMDs                      largest Anemoi-4-3 batch (Jive, permutation, sponge) on the
+ *                                                                                      two-row 2-D kernels (ONE state per wavefront, a column per
+ *                                                                                      row pair: lowest latency); above: coop43_max's kernel
  *   coop_sponge_max        ANEMOI_COOP_SPONGE_MAX       4 x SIMDs                      largest equal-length sponge batch on the cooperative kernel
  *   coop_climb_max         ANEMOI_COOP_CLIMB_MAX        4 x SIMDs                      largest batch of authentication paths on the cooperative kernel
  *   coop_max               ANEMOI_COOP_MAX              0                              one-item-per-wavefront scan kernel (A/B and parity only)

@@ -101,6 +101,37 @@ def test_bounds_of_a_round(moduli, params):
             assert x < cap and y < cap
         jive = 2 * (x + y)                               # state[0] + state[1] + elems (all four below max(x, y))
         assert jive / H + 1 < 2, (f, "mul_exact for to_abi must end below 2p")
+        # Anemoi-4-3 on the same arithmetic (a column per row pair): the linear layer of two columns, mds_layer arm 2
+        # (src/traits.rs:143-157), with g * v taken as a PRODUCT (mul_g_settled) so that the sums stay small
+        x0 = x1 = y0 = y1 = S
+        for _ in range(3):
+            x0, x1, y0, y1 = x0 + 1, x1 + 1, y0 + 1, y1 + 1
+            x0 = x0 + mul(x1, Fr(1))                     # s0 += g s1
+            x1 = x1 + mul(x0, Fr(1))                     # s1 += g s0
+            y1 = y1 + mul(y0, Fr(1))                     # s3 += g s2
+            y0 = y0 + mul(y1, Fr(1))                     # s2 += g s3
+            y0, y1 = y1, y0                              # swap(s2, s3)
+            y0, y1 = y0 + x0, y1 + x1                    # s2 += s0 ; s3 += s1
+            x0, x1 = x0 + y0, x1 + y1                    # s0 += s2 ; s1 += s3
+            assert max(x0, x1, y0, y1) < cap, (f, "4-3 linear layer", float(max(x0, x1, y0, y1)), float(cap))
+            cols = []
+            for xc, yc in ((x0, y0), (x1, y1)):          # settle, then the S-box of each column as above
+                xc, yc = mul(xc, Fr(1)), mul(yc, Fr(1))
+                t = mul(yc, yc)
+                assert g * t <= K
+                xc = xc + K
+                pw = mul(xc, xc)
+                for _ in range(40):
+                    pw = mul(max(pw, xc), max(pw, xc))
+                assert pw <= K
+                yc = yc + K
+                t = mul(yc, yc)
+                xc = xc + g * t + 1
+                assert xc < cap and yc < cap
+                cols.append((xc, yc))
+            (x0, y0), (x1, y1) = cols
+        jive4 = 2 * (x0 + y0 + x1 + y1)                  # compress_k(., 4): all four sums and the elements
+        assert jive4 / H + 1 < 2, (f, "mul_exact for to_abi must end below 2p (4-3)")
         bits = math.ceil(math.log2(worst_in[0]))
         assert (1 << bits) * L.p < L.R
         rng = random.Random(5)

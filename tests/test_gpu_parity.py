@@ -31,12 +31,13 @@ def rand_elems(oracle, fid, modulus, count, seed):
     return oracle.ints_to_mont(fid, [rng.randrange(modulus) for _ in range(count)])
 
 
-# small batches take the cooperative latency kernels by default -- the two-row fold kernels (coop2d.h) for Anemoi-2-1,
-# the row-cooperative scan kernels for 4-3; "row" switches the fold kernels off (2-1 on the row-cooperative scan
+# small batches take the cooperative latency kernels by default -- the two-row fold kernels (coop2d.h: two 2-1 items or
+# one 4-3 state per wavefront); "row" switches the fold kernels off (everything on the row-cooperative scan
 # kernels), "lane" forces the lane-private throughput kernels.  (The one-item-per-wavefront kernels -- four-row fold /
 # scan -- are forced in test_cooperative_and_lane_private_paths_agree and in the fuzz.)
-LATENCY_KERNELS = {"default": {}, "row": {"coop_max": 0, "coop2d_max": 0}, "lane": {"coop_max": 0, "coop2d_max": 0, "coop4_max": 0, "coop43_max": 0,
-                                           "coop_sponge_max": 0, "coop_climb_max": 0}}
+LATENCY_KERNELS = {"default": {}, "row": {"coop_max": 0, "coop2d_max": 0, "coop2d43_max": 0},
+                   "lane": {"coop_max": 0, "coop2d_max": 0, "coop4_max": 0, "coop43_max": 0, "coop2d43_max": 0,
+                            "coop_sponge_max": 0, "coop_climb_max": 0}}
 
 
 # ---------------------------------------------------------------- (1) the reference's own KATs
@@ -454,15 +455,29 @@ for fid, field in enumerate(A.FIELD_IDS):
         for k in (2, 4):
             got = A.Anemoi(field, 4).compress_k_batch(st, k)
             assert (got == oracle.compress_batch(fid, 4, st, k=k, threads=8)).all(), (field, n, k)
+    # the other Anemoi-4-3 latency kernels under the same forcing: permutation, sponge (bytes / elements)
+    inst4 = A.Anemoi(field, 4)
+    st = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(4 * 3)]).reshape(3, 4, L)
+    pg = inst4.permutation_batch(st)
+    assert all((pg[i] == oracle.permutation(fid, 4, st[i])).all() for i in range(3)), field
+    for ln in (0, 1, inst4.chunk, 3 * inst4.chunk - 1, 3 * inst4.chunk, 3 * inst4.chunk + 1, 200):
+        msgs = np.frombuffer(rng.randbytes(3 * ln), dtype=np.uint8).reshape(3, ln) if ln else np.zeros((3, 0), dtype=np.uint8)
+        assert (inst4.hash_batch(msgs) == oracle.hash_bytes_batch(fid, 4, msgs, threads=1)).all(), (field, ln)
+    for ne in (0, 1, 3, 4, 7):
+        el = oracle.ints_to_mont(fid, [rng.randrange(p) for _ in range(3 * ne)]).reshape(3, ne, L)
+        assert (inst4.hash_field_batch(el) == oracle.hash_field_batch(fid, 4, el, threads=1)).all(), (field, ne)
 print("ok")
 '''.replace("ROOT", repr(ROOT))
-    # (one-per-wavefront scan, two-row fold, row-cooperative scan 2-1, row-cooperative 4-3): each forced for every size
-    for coop_max, coop2d_max, coop4_max, coop43_max in (("0", "0", "0", "0"), ("1000000000", "0", "0", "1000000000"),
-                                                         ("0", "0", "1000000000", "1"), ("0", "1000000000", "0", "0")):
+    # (lane-private; one-per-wavefront + row-cooperative 4-3; row-cooperative scan 2-1; two-row fold 2-1 AND 4-3): each
+    # forced for every size
+    for coop_max, coop2d_max, coop4_max, coop43_max, coop2d43_max in (
+            ("0", "0", "0", "0", "0"), ("1000000000", "0", "0", "1000000000", "0"), ("0", "0", "1000000000", "1", "0"),
+            ("0", "1000000000", "0", "0", "1000000000")):
         env = dict(os.environ, ANEMOI_COOP_MAX=coop_max, ANEMOI_COOP2D_MAX=coop2d_max, ANEMOI_COOP4_MAX=coop4_max,
-                   ANEMOI_COOP43_MAX=coop43_max)
+                   ANEMOI_COOP43_MAX=coop43_max, ANEMOI_COOP2D43_MAX=coop2d43_max)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-        assert out.returncode == 0 and "ok" in out.stdout, (coop_max, coop2d_max, coop4_max, coop43_max, out.stdout[-1500:], out.stderr[-1500:])
+        assert out.returncode == 0 and "ok" in out.stdout, (coop_max, coop2d_max, coop4_max, coop43_max, coop2d43_max,
+                                                            out.stdout[-1500:], out.stderr[-1500:])
 
 
 def test_concurrent_callers(A, oracle, params):

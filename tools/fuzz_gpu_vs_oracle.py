@@ -3,7 +3,7 @@
 
   Jive 2-1      lane-private, two-row fold (coop2d), row-cooperative scan, one item per wavefront (four-row fold on the
                 11-limb fields, the scan on the 15-limb ones)
-  Jive 4-3      lane-pair and row-cooperative, k = 2 and 4
+  Jive 4-3      lane-pair, row-cooperative and two-row fold (one state per wavefront), k = 2 and 4
   permutation   the default routing of the batch size
   sponge        two-row / row-cooperative / lane-private kernels on equal-length batches, the ragged kernel on all
                 lengths in one batch, the segment-fed host path (tiny forced segments)
@@ -28,7 +28,7 @@ for _p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "anemoi-rust_amd")):
 import numpy as np
 
 BIG = 1 << 40
-LANE = dict(coop_max=0, coop2d_max=0, coop4_max=0, coop43_max=0, coop_sponge_max=0, coop_climb_max=0)
+LANE = dict(coop_max=0, coop2d_max=0, coop4_max=0, coop43_max=0, coop2d43_max=0, coop_sponge_max=0, coop_climb_max=0)
 
 
 def structured_values(p):
@@ -93,9 +93,13 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
                     ok = (inst.compress_batch(st) == exp).all() and (inst.compress_k_batch(st, 4) == exp4).all()
                 msg += " lane-pair %s" % check(ok, (field, width, "lane-pair"))
                 m = min(cnt, 1501)
-                with A.options(coop43_max=BIG):
+                with A.options(coop43_max=BIG, coop2d43_max=0):
                     ok = (inst.compress_batch(st[:m]) == exp[:m]).all() and (inst.compress_k_batch(st[:m], 4) == exp4[:m]).all()
                 msg += "  row-coop(%d) k=2,4 %s" % (m, check(ok, (field, width, "row-coop 4-3")))
+                m = min(cnt, 700)
+                with A.options(coop2d43_max=BIG):
+                    ok = (inst.compress_batch(st[:m]) == exp[:m]).all() and (inst.compress_k_batch(st[:m], 4) == exp4[:m]).all()
+                msg += "  two-row(%d) k=2,4 %s" % (m, check(ok, (field, width, "two-row 4-3")))
             m = min(cnt, 256)
             pg = inst.permutation_batch(st[:m])
             ok = all((pg[i] == oracle.permutation(fid, width, st[i])).all() for i in range(0, m, 5))
@@ -116,8 +120,8 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
                 if ln:
                     msgs[0], msgs[1] = 0, 255
                 exp = oracle.hash_bytes_batch(fid, width, msgs, threads=threads)
-                ok = ok and (inst.hash_batch(msgs) == exp).all()                      # default: two-row fold (2-1), row-coop (4-3)
-                with A.options(coop_max=0, coop2d_max=0):
+                ok = ok and (inst.hash_batch(msgs) == exp).all()                      # default: the two-row fold kernels
+                with A.options(coop_max=0, coop2d_max=0, coop2d43_max=0):
                     ok = ok and (inst.hash_batch(msgs) == exp).all()                  # row-cooperative sponge
                 with A.options(**LANE):
                     ok = ok and (inst.hash_batch(msgs) == exp).all()                  # lane-private sponge

@@ -82,14 +82,14 @@ for field in fields:
                 continue
             print("    coop2d <= %5d, coop4 <= %5d: %7.2f ms" % (c2max, c4max, tree_ms(depth, c2max, c4max)))
 
-# ---- Anemoi-4-3: row-cooperative (two states per wavefront) against the lane-pair kernel ---------------------------
+# ---- Anemoi-4-3: two-row fold (one state per wavefront) / row-cooperative scan (two) / the lane-pair kernel ---------------------------
 for field in [f for f in fields if f in ("bn_254", "bls12_381", "jubjub")] or ["bn_254", "bls12_381"]:
     fid, L = A.field_id(field), synth.limbs_of(field)
     sizes = [1 << k for k in range(0, 15)]
     st = synth.states(field, 4, 0xC4, 0, sizes[-1])
     d_in = torch.from_numpy(st.view(np.int64).reshape(-1)).to(dev)
     print("%s Anemoi-4-3 Jive (k = 2): kernel time in ms per batch size" % field)
-    print("%8s %10s %10s   best" % ("states", "row-coop", "lane-pair"))
+    print("%8s %10s %10s %10s   best" % ("states", "two-row", "row-coop", "lane-pair"))
 
     def timed43(n, d_out):
         ts = []
@@ -104,16 +104,21 @@ for field in [f for f in fields if f in ("bn_254", "bls12_381", "jubjub")] or ["
 
     for n in sizes:
         row, ref = {}, None
-        for mode, cmax in (("row-coop", BIG), ("lane-pair", 0)):
+        for mode, cmax, c2d in (("two-row", 0, BIG), ("row-coop", BIG, 0), ("lane-pair", 0, 0)):
+            if mode == "two-row" and n > 8192:
+                continue
             A.set_option("coop43_max", cmax)
+            A.set_option("coop2d43_max", c2d)
             d_out = torch.zeros(n * 2 * L, dtype=torch.int64, device=dev)
             row[mode] = timed43(n, d_out)
             got = d_out.cpu()
             if ref is None:
                 ref = got
             assert torch.equal(ref, got), (field, n, mode)
-        print("%8d %10.3f %10.3f   %s" % (n, row["row-coop"], row["lane-pair"], min(row, key=row.get)))
+        print("%8d %10s %10.3f %10.3f   %s" % (n, "%.3f" % row["two-row"] if "two-row" in row else "-", row["row-coop"],
+                                              row["lane-pair"], min(row, key=row.get)))
     A.set_option("coop43_max", None)
+    A.set_option("coop2d43_max", None)
 
 # ---- sponge: row-cooperative (4 / 2 messages per wavefront) against the lane-private kernels, 1 KB messages ----------
 for field, width in (("jubjub", 2), ("bn_254", 4), ("bls12_381", 2)):
@@ -132,9 +137,9 @@ for field, width in (("jubjub", 2), ("bn_254", 4), ("bls12_381", 2)):
     for n in sizes:
         row, ref = {}, None
         for mode, cmax, c2 in (("two-row", BIG, BIG), ("row-coop", BIG, 0), ("lane", 0, 0)):
-            if mode == "two-row" and width != 2:
+            if mode == "two-row" and width == 4 and n > 4096:
                 continue
-            A.set_option("coop_sponge_max", cmax); A.set_option("coop2d_max", c2)
+            A.set_option("coop_sponge_max", cmax); A.set_option("coop2d_max", c2); A.set_option("coop2d43_max", c2)
             d_out = torch.zeros(n * L, dtype=torch.int64, device=dev)
             ts = []
             for _ in range(3):
@@ -150,4 +155,4 @@ for field, width in (("jubjub", 2), ("bn_254", 4), ("bls12_381", 2)):
                 ref = got
             assert torch.equal(ref, got), (field, n, mode)
         print("%8d %10s %10.3f %10.3f   %s" % (n, "%10.3f" % row["two-row"] if "two-row" in row else "-", row["row-coop"], row["lane"], min(row, key=row.get)))
-    A.set_option("coop_sponge_max", None); A.set_option("coop2d_max", None)
+    A.set_option("coop_sponge_max", None); A.set_option("coop2d_max", None); A.set_option("coop2d43_max", None)
