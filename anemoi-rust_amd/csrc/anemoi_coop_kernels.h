@@ -1,14 +1,15 @@
-// anemoi_coop_kernels.h -- the LATENCY kernels: small batches on the row-cooperative arithmetic of coop29.h (one 29-bit
-// limb per lane, an element per 16-lane DPP row), and the cut-offs that route a launch to them.
+// anemoi_coop_kernels.h -- the LATENCY kernels: small batches on the cooperative arithmetics -- the two-row fold product of
+// coop2d.h (an element on a pair of 16-lane DPP rows; LPR = 32) and the digit-serial scan of coop29.h (one 29-bit limb per
+// lane, an element per row; LPR = 16) -- and the cut-offs that route a launch to them.
 //
-//   k_jive2_coop<F, 16>     Jive::compress 2-1 / Sponge::merge   src/<f>/anemoi_2_1/hasher.rs:86-103    4 items per wavefront
-//   k_jive2_coop<F, 64>     the same, one item per wavefront (rounds 1-2's form; A/B and parity only)
-//   k_jive4_coop<F, K>      Jive::compress(_k) 4-3               src/<f>/anemoi_4_3/hasher.rs:148-179   2 states per wavefront
-//   k_permutation_coop      Anemoi::permutation                  src/traits.rs:370-378
-//   k_merkle_climb_coop     authentication-path verification     (depth x merge)
-//   k_sponge_coop           Sponge::hash / hash_field            anemoi_2_1/hasher.rs:18-85, anemoi_4_3/hasher.rs:19-129
+//   k_jive2_coop<F, LPR>       Jive::compress 2-1 / Sponge::merge   src/<f>/anemoi_2_1/hasher.rs:86-103    2 / 4 items per wavefront
+//   k_jive2_coop<F, 64>        the same, one item per wavefront (four-row fold / rounds 1-2's scan; A/B and parity only)
+//   k_jive4_coop<F, K, LPR>    Jive::compress(_k) 4-3               src/<f>/anemoi_4_3/hasher.rs:148-179   1 / 2 states per wavefront
+//   k_permutation_coop         Anemoi::permutation                  src/traits.rs:370-378
+//   k_merkle_climb_coop        authentication-path verification     (depth x merge)
+//   k_sponge_coop              Sponge::hash / hash_field            anemoi_2_1/hasher.rs:18-85, anemoi_4_3/hasher.rs:19-129
 //
-// All of them are built on coop_permutation (one column (x, y) per row; the 4-3 linear layer couples two rows) and
+// All of them are built on coop_permutation (one column (x, y) per element; the 4-3 linear layer couples two columns) and
 // coop_flystel (the S-box with its sliding-window exponentiation, table in LDS).  Same round function and the same
 // bound bookkeeping as the lane-private kernels of anemoi_kernels.h; every kernel is forced for every size and field
 // against the oracle by tests/test_gpu_parity.py.

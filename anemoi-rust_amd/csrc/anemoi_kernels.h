@@ -8,11 +8,14 @@
 //   k_mont_convert  canonical <-> Montgomery           (arkworks into_bigint / from_bigint)
 // one Anemoi-4-3 state per lane PAIR (both columns' S-boxes run side by side):
 //   k_permutation_pair, k_jive_pair, k_sponge_pair      (all width-4 entry points)
-// a few items per wavefront, one 29-bit limb per lane (latency path for small batches; anemoi_coop_kernels.h, coop29.h):
-//   k_jive2_coop<F, 16>   Jive::compress 2-1 / Sponge::merge, four items per wavefront (one per 16-lane DPP row);
-//                         <F, 64> = rounds 1-2's one item per wavefront, kept for A/B
-//   k_jive4_coop          Jive::compress(_k) 4-3, two states per wavefront (a column per row)
-//   k_sponge_coop         Sponge::hash / hash_field on small batches of equal-length messages
+// a few items per wavefront, one limb per lane (latency path for small batches; anemoi_coop_kernels.h), on two arithmetics --
+// LPR = 32: the two-row fold product of coop2d.h (an element on a pair of 16-lane DPP rows: the lowest latency),
+// LPR = 16: the digit-serial scan of coop29.h (an element per row: twice the items per wavefront):
+//   k_jive2_coop<F, LPR>       Jive::compress 2-1 / Sponge::merge: two (32) / four (16) items per wavefront;
+//                              <F, 64> = one item per wavefront (four-row fold / rounds 1-2's scan), kept for A/B
+//   k_jive4_coop<F, K, LPR>    Jive::compress(_k) 4-3: one state per wavefront, a column per row pair (32) / two, a column
+//                              per row (16)
+//   k_sponge_coop              Sponge::hash / hash_field on small batches of equal-length messages (both widths, both LPR)
 //   k_permutation_coop, k_merkle_climb_coop   Anemoi::permutation / path verification on small batches
 // instances given by run-time trait constants, one state per NUM_COLUMNS lanes (anemoi_generic.h):
 //   k_permutation_cols, k_jive_cols, k_sponge_cols, and the element-wise k_exp_alpha
