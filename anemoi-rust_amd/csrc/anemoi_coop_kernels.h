@@ -127,43 +127,6 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typ
         acc = C::mul(acc, b, k);
       }
     };
-#if defined(ANEMOI_COOP_LOOP_V1)
-    if constexpr (F::kCoopRegular && F::kCoopPrefix == 0) {
-      const int body = pc.steps5 - 1;
-#pragma nounroll
-      for (int s = 0; s < body; s++) {
-        const uint32_t after = uniform_word(pc.sched5, s + 2);
-        const uint32_t opnd_next = operand_of(next);
-        acc = C::sqr_mul(acc, word & 0xff, opnd, k);
-        word = next, next = after, opnd = opnd_next;
-      }
-      if ((word >> 8) == 255) acc = C::sqr_n(acc, word & 0xff, k);
-      else acc = C::sqr_mul(acc, word & 0xff, opnd, k);
-    } else {
-#pragma nounroll
-      for (int s = 0; s < pc.steps5; s++) {
-        const uint32_t after = uniform_word(pc.sched5, s + 2);
-        const uint32_t opnd_next = operand_of(next);
-        const uint32_t nsq = word & 0xff, idx = word >> 8;
-        uint32_t b = opnd;
-        word = next, next = after, opnd = opnd_next;
-        if constexpr (F::kChainTmp) {
-          if (idx == 253) {
-            tmp = acc;
-            continue;
-          }
-          b = idx == 254 ? tmp : b;
-        }
-        if (idx == 255) {
-          if (nsq) acc = C::sqr_n(acc, nsq, k);
-        } else if (nsq) {
-          acc = C::sqr_mul(acc, nsq, b, k);
-        } else {
-          acc = C::mul(acc, b, k);
-        }
-      }
-    }
-#else
     constexpr int kGeneral = F::kCoopRegular ? F::kCoopPrefix : 1 << 30;   // steps that go through the general form
     int s = 0;
 #pragma nounroll
@@ -175,9 +138,7 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typ
     }
     if constexpr (F::kCoopRegular) {
       // the regular tail, every step but the last: squarings, then a table multiplication -- no decoding, no branches
-#if !defined(ANEMOI_COOP_TAIL_UNROLL)
 #pragma nounroll
-#endif
       for (; s < pc.steps5 - 1; s++) {
         const uint32_t after = uniform_word(pc.sched5, s + 2);
         const uint32_t opnd_next = operand_of(next);
@@ -187,7 +148,6 @@ __device__ __forceinline__ void coop_flystel(uint32_t& x, uint32_t& y, const typ
       if ((word >> 8) == 255) acc = C::sqr_n(acc, word & 0xff, k);   // the trailing squarings of the exponent
       else acc = C::sqr_mul(acc, word & 0xff, opnd, k);
     }
-#endif
     t = acc;
   }
   y = C::sub(y, t, k);
