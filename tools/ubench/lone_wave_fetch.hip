@@ -110,6 +110,14 @@ TIMED(k_vs_scmp, ".rept 16\n\t" R8(VS_SCMP) ".endr\n\t", 384)
 TIMED(k_gap_smov, GAP("s_mov_b32 s91, 0x7fffffff\n\t"), 224)
 TIMED(k_gap_snop0, GAP("s_nop 0\n\t"), 224)
 
+// 64-bit shifts and multiplies of the lane-private product
+#define LSHR64(i) "v_lshrrev_b64 %" #i ", 30, %" #i "\n\t"
+#define MULLO(i) "v_mul_lo_u32 %" #i ", %13, %" #i "\n\t"
+TIMED(k_lshr64, ".rept 64\n\t" LSHR64(8) LSHR64(9) LSHR64(10) LSHR64(11) ".endr\n\t", 256)
+TIMED(k_mullo, X32(R8(MULLO)), 256)
+// a column of the lane-private squaring: multiply-adds, then the carry shift, dependent
+TIMED(k_column, ".rept 32\n\t" MAD(8) MAD(8) MAD(8) MAD(8) MAD(8) MAD(8) MAD(8) LSHR64(8) ".endr\n\t", 256)
+
 // taken branches: K e32 adds (4 B each), then an unconditional branch to the next group; target aligned to 64 B,
 // or deliberately 4 B before a 64 B boundary
 #define GROUP_ALIGNED(K) ".rept 16\n\t.p2align 6\n\t.rept " #K "\n\tv_add_u32_e32 %0, %13, %0\n\t.endr\n\ts_branch 1f\n\t.p2align 6\n\t1:\n\t.endr\n\t"
@@ -148,6 +156,7 @@ int main() {
                   {"(v_add, s_add, s_nop 0) x", k_vs_sadd}, {"(v_add, s_mov literal) x", k_vs_smovlit},
                   {"(v_add, s_nop 0, s_nop 0) x", k_vs_snop}, {"(v_add, s_cmp, s_nop 0) x", k_vs_scmp},
                   {"add a, mad, s_mov literal, dpp reads a, 3 mads", k_gap_smov}, {"add a, mad, s_nop 0, dpp reads a, 3 mads", k_gap_snop0},
+                  {"v_lshrrev_b64 (8 B)", k_lshr64}, {"v_mul_lo_u32 (8 B)", k_mullo}, {"7 dependent mads + v_lshrrev_b64", k_column},
                   {"8 adds + taken branch, aligned", k_br_a8}, {"32 adds + taken branch, aligned", k_br_a32},
                   {"8 adds + taken branch, target at line end", k_br_u8}, {"32 adds + taken, target at line end", k_br_u32},
                   {"8 adds + cmp + not-taken branch", k_nt8},
