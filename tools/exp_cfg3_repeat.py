@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Why is the FIRST config-3 launch of a process 46 % slower in KERNEL time (rocprofv3: 487 ms against 333 ms)?
+Experiment: warm the same kernel with a small batch first / touch the message buffer first / neither.
+    python tools/exp_cfg3_repeat.py [warm_kernel] [touch_msgs]
+"""
+import ctypes, os, sys, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = ctypes.CDLL(os.path.join(ROOT, "anemoi-rust_amd", "lib", "libanemoi_mi355x.so"))
+vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+lib.anemoi_hash_bytes_dev.argtypes = [ci, ci, vp, sz, sz, vp, vp]
+dev = torch.device("cuda", 0); st = torch.cuda.current_stream(); s = st.cuda_stream
+rng = np.random.default_rng(7)
+nmsg = 1 << 16
+msgs = torch.from_numpy(rng.integers(0, 256, size=(nmsg, 10240), dtype=np.uint8)).to(dev)
+dig = torch.empty(nmsg * 4, dtype=torch.int64, device=dev)
+torch.cuda.synchronize()
+
+def timed(n, ln):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(st)
+    assert lib.anemoi_hash_bytes_dev(2, 4, msgs.data_ptr(), ln, n, dig.data_ptr(), s) == 0
+    b.record(st)
+    torch.cuda.synchronize()
+    return round(a.elapsed_time(b), 1)
+
+if "warm_kernel" in sys.argv:
+    print("warm-up: 2^15 messages of 93 bytes (the same kernel):", timed(1 << 15, 93), "ms, again", timed(1 << 15, 93))
+if "touch_msgs" in sys.argv:
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(st); chk = int(msgs.view(torch.int64).sum().item()); b.record(st); torch.cuda.synchronize()
+    print("touched the message buffer (a torch reduction): %.1f ms" % a.elapsed_time(b))
+print("config 3, three calls:", [timed(nmsg, 10240) for _ in range(3)])
