@@ -25,6 +25,10 @@ def timed(n, ln):
 
 if "warm_kernel" in sys.argv:
     print("warm-up: 2^15 messages of 93 bytes (the same kernel):", timed(1 << 15, 93), "ms, again", timed(1 << 15, 93))
+for a in sys.argv[1:]:
+    if a.startswith("warm="):          # warm=<messages>: a warm-up launch of the same kernel on that many 93-byte messages
+        n = int(a[5:])
+        print("warm-up: %d messages of 93 bytes:" % n, timed(n, 93), "ms")
 if "touch_msgs" in sys.argv:
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(st); chk = int(msgs.view(torch.int64).sum().item()); b.record(st); torch.cuda.synchronize()
