@@ -474,3 +474,51 @@ def test_committed_header_is_what_the_generator_writes():
     with contextlib.redirect_stdout(io.StringIO()):
         G.main()
     assert open(path).read() == before, "csrc/coop2d_asm_gen.h is stale: run tools/gen_coop2d_asm.py"
+
+
+def test_issue_slots_of_the_generated_statements_do_not_regress():
+    """The latency of a compression is the issue-slot count of its products: pin what the generator
+    achieves today -- 78 / 79 slots per multiplication / squaring on 11 limbs, 96 / 97 on 15, six wait slots left per
+    squaring -- so that an edit of the generator that costs a slot is noticed here, not on the GPU."""
+    want = {(11, 2): (78, 79), (15, 2): (96, 97), (11, 4): (83, 86)}
+    for (nl, rows), (mul_slots, sqr_slots) in want.items():
+        W = dict(G.LAYOUTS)[nl]
+        assert G.gen_product(nl, W, "mul", rows)[2]["slots"] <= mul_slots, (nl, rows)
+        for kind in ("sqr_run", "sqr_mul"):
+            lines, _, info = G.gen_product(nl, W, kind, rows)
+            assert info["slots"] <= sqr_slots, (nl, rows, kind, info["slots"])
+            assert info["off_grid"] == 0
+        if rows == 2:
+            assert G.gen_product(nl, W, "sqr_run", rows)[2]["nops"] <= 6 * G.UNROLL
+
+
+def test_the_fetch_grid_pass_is_optimal_on_small_texts():
+    """tools/asm_grid.align8 against brute force: random short instruction lists (4-byte promotable / splittable /
+    fixed, 8-byte) -- the dynamic programme leaves as few 8-byte instructions off the grid as any choice of encodings."""
+    import itertools
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_grid
+    pool = ["v_add_u32 v1, v2, v3", "s_sub_u32 s4, s4, 1", "s_nop 1", "s_nop 0", "v_mad_u64_u32 v[2:3], vcc, v4, v5, v[2:3]",
+            "v_mov_b32_dpp v1, v2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1", "v_and_b32 v1, 0x7ffffff, v2",
+            "s_cbranch_scc1 1b", "v_lshrrev_b32 v1, 27, v2"]
+    rng = random.Random(12)
+    for trial in range(200):
+        text = [rng.choice(pool) for _ in range(rng.randrange(1, 9))]
+        for vnop in (False, True):
+            got_lines, got = asm_grid.align8(text, vnop=vnop)
+            options = [asm_grid._variants(ln, vnop) for ln in text]
+            best = None
+            for pick in itertools.product(*[range(len(o)) for o in options]):
+                off, cost = 0, 0
+                for o, i in zip(options, pick):
+                    size = o[i][1]
+                    cost += 1 if size == 8 and off % 8 else 0
+                    off += size
+                best = cost if best is None else min(best, cost)
+            assert got == best, (text, vnop, got, best)
+            off = bad = 0
+            for ln in got_lines:
+                size = asm_grid.enc_size(ln)
+                bad += 1 if size == 8 and off % 8 else 0
+                off += size
+            assert bad == got, (text, got_lines)
