@@ -58,10 +58,11 @@ inline size_t coop_max_items() { return size_t(opt::get_or(opt::kCoopMax, 0)); }
 inline size_t coop2d_max_items(int simds) { return size_t(opt::get_or(opt::kCoop2dMax, 2ll * simds)); }
 inline size_t coop4_max_items(int simds) { return size_t(opt::get_or(opt::kCoop4Max, 8ll * simds)); }
 // Anemoi-4-3: batches up to this many states take the row-cooperative kernel k_jive4_coop (two states per wavefront),
-// larger ones the lane-pair kernel (sweep: BN-254 1.17 vs 1.64 ms at 2 048 states, 1.68 vs 1.66 at 4 096; BLS12-381
-// 3.35 vs 4.84 ms at 4 096, 5.95 vs 4.85 at 8 192): one wavefront per SIMD on 9 limbs, two on 14
-inline size_t coop43_max_items(int simds, int limbs29) {
-  return size_t(opt::get_or(opt::kCoop43Max, (limbs29 >= 14 ? 4ll : 2ll) * simds));
+// larger ones the lane-pair kernel: two wavefronts per SIMD on every field (profiles/r04/coop_kernel_sweep.txt: 4 096
+// states BN-254 1.44 vs 1.57 ms, Jubjub 1.43 vs 1.53, BLS12-381 3.06 vs 4.29; 8 192: 2.65 vs 1.58, 5.74 vs 4.29 -- round
+// 3 stopped the 9-limb fields at 2 048, where the two were level before the statements sat on the fetch grid)
+inline size_t coop43_max_items(int simds, int /*limbs29*/) {
+  return size_t(opt::get_or(opt::kCoop43Max, 4ll * simds));
 }
 // Anemoi-4-3 batches (Jive, permutation, equal-length sponge) up to this many states take the two-row fold kernels with
 // ONE state per wavefront (a column per row pair): one wavefront per SIMD

@@ -107,8 +107,7 @@ int anemoi_release(int device);
  *                                                                                      wavefront, lowest latency); 0 = never
  *   coop4_max              ANEMOI_COOP4_MAX             8 x SIMDs                      largest Jive 2-1 / permutation batch on the row-cooperative
  *                                                                                      kernel (four items per wavefront); above: lane-private
- *   coop43_max             ANEMOI_COOP43_MAX            2 x SIMDs (4-limb fields),     the same for Anemoi-4-3 (two states per wavefront)
- *                                                       4 x SIMDs (6-limb)
+ *   coop43_max             ANEMOI_COOP43_MAX            4 x SIMDs                      the same for Anemoi-4-3 (two states per wavefront)
  *   coop2d43_max           ANEMOI_COOP2D43_MAX          1 x SIMDs                      largest Anemoi-4-3 batch (Jive, permutation, sponge) on the
  *                                                                                      two-row 2-D kernels (ONE state per wavefront, a column per
  *                                                                                      row pair: lowest latency); above: coop43_max's kernel
