@@ -23,7 +23,7 @@
                  : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7),          \
                    "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)                                                   \
                  : "s"(iters), "v"(x), "s"(msk)                                                             \
-                 : "s90", "s91", "scc", "vcc");                                                             \
+                 : "s90", "s91", "s92", "s93", "scc", "vcc");                                                             \
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(q1)::"memory"); \
     asm volatile("" ::"v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(r6), "v"(r7), "v"(w0),      \
                  "v"(w1), "v"(w2), "v"(w3));                                                                \
@@ -118,6 +118,12 @@ TIMED(k_mullo, X32(R8(MULLO)), 256)
 // a column of the lane-private squaring: multiply-adds, then the carry shift, dependent
 TIMED(k_column, ".rept 32\n\t" MAD(8) MAD(8) MAD(8) MAD(8) MAD(8) MAD(8) MAD(8) LSHR64(8) ".endr\n\t", 256)
 
+// Does a wavefront with only half (or a quarter) of its lanes enabled issue faster?  (EXEC = low 32 / low 16 lanes)
+TIMED(k_exec32, "s_mov_b64 s[92:93], exec\n\ts_mov_b64 exec, 0xffffffff\n\t" X32(R8(ADD64)) "s_mov_b64 exec, s[92:93]\n\t", 256)
+TIMED(k_exec16, "s_mov_b64 s[92:93], exec\n\ts_mov_b64 exec, 0xffff\n\t" X32(R8(ADD64)) "s_mov_b64 exec, s[92:93]\n\t", 256)
+TIMED(k_exec32_mad, "s_mov_b64 s[92:93], exec\n\ts_mov_b64 exec, 0xffffffff\n\t" ".rept 64\n\t" R4M ".endr\n\t" "s_mov_b64 exec, s[92:93]\n\t", 256)
+TIMED(k_exec32_dpp, "s_mov_b64 s[92:93], exec\n\ts_mov_b64 exec, 0xffffffff\n\t" X32(R8(DPP)) "s_mov_b64 exec, s[92:93]\n\t", 256)
+
 // taken branches: K e32 adds (4 B each), then an unconditional branch to the next group; target aligned to 64 B,
 // or deliberately 4 B before a 64 B boundary
 #define GROUP_ALIGNED(K) ".rept 16\n\t.p2align 6\n\t.rept " #K "\n\tv_add_u32_e32 %0, %13, %0\n\t.endr\n\ts_branch 1f\n\t.p2align 6\n\t1:\n\t.endr\n\t"
@@ -157,6 +163,8 @@ int main() {
                   {"(v_add, s_nop 0, s_nop 0) x", k_vs_snop}, {"(v_add, s_cmp, s_nop 0) x", k_vs_scmp},
                   {"add a, mad, s_mov literal, dpp reads a, 3 mads", k_gap_smov}, {"add a, mad, s_nop 0, dpp reads a, 3 mads", k_gap_snop0},
                   {"v_lshrrev_b64 (8 B)", k_lshr64}, {"v_mul_lo_u32 (8 B)", k_mullo}, {"7 dependent mads + v_lshrrev_b64", k_column},
+                  {"v_add_u32, EXEC = low 32 lanes", k_exec32}, {"v_add_u32, EXEC = low 16 lanes", k_exec16},
+                  {"v_mad_u64_u32, EXEC = low 32 lanes", k_exec32_mad}, {"v_mov_b32_dpp, EXEC = low 32 lanes", k_exec32_dpp},
                   {"8 adds + taken branch, aligned", k_br_a8}, {"32 adds + taken branch, aligned", k_br_a32},
                   {"8 adds + taken branch, target at line end", k_br_u8}, {"32 adds + taken, target at line end", k_br_u32},
                   {"8 adds + cmp + not-taken branch", k_nt8},
