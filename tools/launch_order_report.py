@@ -7,8 +7,7 @@ from a fast dispatch of the SAME kernel on the same grid --
                      sum over the XCDs; good to ~3 % on dispatches of >= 10 ms)
   Mcycles          = GRBM_GUI_ACTIVE / 8: a dispatch that is slow at EQUAL cycles was slow because of the clock
   waves / SIMD     = SQ_WAVE_CYCLES x 4 / (cycles x 1 024 SIMDs): average residency
-  busy CUs         = SQ_BUSY_CU_CYCLES / (cycles x 256 CUs) where collected (the counter reads 4 per busy CU-cycle on gfx950: /4): < 1 means part of
-                     the chip held no wavefront
+  busy CUs         = SQ_BUSY_CU_CYCLES / (cycles x 256 CUs) where collected: < 1 means part of the chip held no wavefront
   cycles / VALU    = cycles x 1 024 / (SQ_INSTS_VALU): per SIMD
 
     python tools/launch_order_report.py <dir with *counter_collection.csv> [--min-ms 1.0]
@@ -46,7 +45,7 @@ def main():
             continue
         cyc = e["GRBM_GUI_ACTIVE"] / XCDS
         wps = e.get("SQ_WAVE_CYCLES", 0.0) * 4 / (cyc * SIMDS)
-        bcu = ("%8.3f" % (e["SQ_BUSY_CU_CYCLES"] / 4 / (cyc * CUS))) if "SQ_BUSY_CU_CYCLES" in e else "       -"
+        bcu = ("%8.3f" % (e["SQ_BUSY_CU_CYCLES"] / (cyc * CUS))) if "SQ_BUSY_CU_CYCLES" in e else "       -"
         cpv = ("%9.2f" % (cyc * SIMDS / e["SQ_INSTS_VALU"])) if e.get("SQ_INSTS_VALU") else "        -"
         print("%4d %-28s %9d %10.1f %9.2f %7.3f %9.2f %9.2f %s %s" % (k, e["kernel"][:28], e["grid"], (e["start"] - t0) / 1e6,
                                                                      e["ms"], cyc / e["ms"] / 1e6, cyc / 1e6, wps, bcu, cpv))
