@@ -23,12 +23,19 @@ namespace anemoi {
 //   32   the two-row fold product of coop2d.h (two items per wavefront)
 //   64   one item per wavefront (A/B and parity only): the FOUR-row fold product where it exists (11-limb fields), else
 //        the one-element scan of coop29.h (rounds 1-2's kernel)
+#ifdef ANEMOI_BOUNDS_WALK   // host walk of the bounds (tests/cpp/bounds_walk): a recording arithmetic in place of both
+template <class F, int LPI>
+struct BoundsWalkCoop;
+template <class F, int LPI, bool FOUR_ROWS = false>
+struct CoopArith { using type = BoundsWalkCoop<F, LPI>; };
+#else
 template <class F, int LPI, bool FOUR_ROWS = (F::Fold::Q4 > 0)>
 struct CoopArith { using type = Coop29<F, LPI>; };
 template <class F, bool FR>
 struct CoopArith<F, 32, FR> { using type = Coop2d<F, 2>; };
 template <class F>
 struct CoopArith<F, 64, true> { using type = Coop2d<F, 4>; };
+#endif
 
 // ---- wave-cooperative Jive 2-to-1 compression (coop29.h, coop2d.h) ------------------------------------
 // Latency path: small batches (the top levels of a Merkle tree, a single Jive::compress / Sponge::merge call).
@@ -162,11 +169,13 @@ struct CoopArk {
   __device__ static __forceinline__ const uint32_t* c(const PermConsts& pc) { return pc.coop_c; }
   __device__ static __forceinline__ const uint32_t* d(const PermConsts& pc) { return pc.coop_d; }
 };
+#ifndef ANEMOI_BOUNDS_WALK
 template <class F, int ROWS>
 struct CoopArk<Coop2d<F, ROWS>> {
   __device__ static __forceinline__ const uint32_t* c(const PermConsts& pc) { return pc.fold_c; }
   __device__ static __forceinline__ const uint32_t* d(const PermConsts& pc) { return pc.fold_d; }
 };
+#endif
 
 // Anemoi::permutation (src/traits.rs:370-378) on the cooperative arithmetic, for one column (x, y) per element row.
 //   W = 2: the state is (x, y); mds_layer arm NUM_COLUMNS = 1 (src/traits.rs:136-142).

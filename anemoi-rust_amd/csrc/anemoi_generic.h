@@ -18,9 +18,11 @@
 //     host-pointer entry points, per anemoi_generic_prepare() handle for the device-pointer ones.  Round 2
 //     converted them on every use: c + 2 extra products per lane per round.
 //
-// Loose bounds (units of p, mont29.h): matrix entries and state < 2 -> products < 2 -> row sums
-// < 2c <= 32 (c <= 16) -> y'' < 64 -> settled before the PHT step so that x'' < 6, y'' < 4; both are
-// settled again to < 2 for the S-box.
+// Loose bounds (mont29.h; walked for 1 .. 16 columns and ANY matrix of canonical entries in BOUNDS.md, tests/test_bounds_walk.py):
+// a row sum is c products of a state element (< 12.4 p after the round constant) by a prepared entry (< 1.02 p), each
+// < 1.2 p, so < 17.8 p at 16 columns on Jubjub (H = 70.7: 25 % of R'); it is settled BEFORE the PHT step, the PHT sums
+// (< 3.6 p) are settled again for the S-box.  k_jive_cols' sum of up to 2c = 32 settled values (< 32.7 p, 47 % of
+// Jubjub's R') goes straight into to_abi's product (A B / H <= 0.26).
 //
 // Also here: k_exp_alpha, the element-wise x^ALPHA (exp_by_alpha, src/traits.rs:94-104) and
 // x^(1/ALPHA) (exp_by_inv_alpha), the pair the reference's `test_alpha` checks against each other.

@@ -31,8 +31,10 @@
 #include <vector>
 
 #include "anemoi_perm.h"
+#ifndef ANEMOI_BOUNDS_WALK   // (the host walk brings its own recording arithmetic for the latency kernels)
 #include "coop29.h"
 #include "coop2d.h"
+#endif
 #include "options.h"
 
 namespace anemoi {
@@ -637,6 +639,7 @@ __global__ __launch_bounds__(kBlock) void k_mont_convert(const uint4* __restrict
 namespace anemoi {
 
 // ---- launchers (one set per field translation unit) ------------------------------------------------
+#ifndef ANEMOI_BOUNDS_WALK
 
 struct HostConsts {  // what the context uploads for one (field, width)
   std::vector<uint32_t> ark_c, ark_d;    // lane-private limb layout (F::Lane)
@@ -971,4 +974,5 @@ struct Launch {
   }
 };
 
+#endif  // ANEMOI_BOUNDS_WALK
 }  // namespace anemoi

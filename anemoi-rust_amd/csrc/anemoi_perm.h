@@ -45,9 +45,18 @@ __device__ __forceinline__ void static_for(Fn&& fn) {
 #ifndef ANEMOI_ARITH32_FIELDS
 #define ANEMOI_ARITH32_FIELDS 0
 #endif
+#ifdef ANEMOI_BOUNDS_WALK
+// tests/cpp/bounds_walk: the kernel bodies compiled for the HOST over an arithmetic that records every operation, so
+// that the lazy-reduction bounds are walked on the code the kernels are made of (tests/test_bounds_walk.py)
+template <class F>
+struct BoundsWalkArith;
+template <int FIELD>
+using ArithFor = BoundsWalkArith<FieldC<FIELD>>;
+#else
 template <int FIELD>
 using ArithFor = std::conditional_t<((ANEMOI_ARITH32_FIELDS >> FIELD) & 1) == 0, Arith29<FieldC<FIELD>>,
                                     Arith32<FieldC<FIELD>>>;
+#endif
 
 // Per-lane window table in LDS: entries 1.. = x^3, x^5, ...; entry e, slot q of this lane at
 // base[((e-1) * NQ + q) * stride].
@@ -204,16 +213,16 @@ __device__ __forceinline__ void exp_inv_alpha(typename A::Fe& r, const typename 
 }
 
 // Flystel S-box on one column (src/traits.rs:326-358).
-// Loose bounds (units of p), entering with x, y < 2 after settle(); a Montgomery product of inputs
-// < A p and < B p is < (A B / H + 1) p with H = R'/p:
-//   381/377-bit fields on 29-bit limbs (H >= 2^25, g*x by limb-wise scaling, subtraction pads with 64 p):
-//     u = g*y^2 < 2g <= 30 ; x' = x + 64p - u < 66 ; t = x'^(1/alpha) < 2 ; y' = y + 64p - t < 66 ;
-//     x'' = x' + g*y'^2 + delta < 66 + 30 + 1 = 97          (every product has A B <= 66^2 << H)
-//   253..255-bit fields and BLS12-377 on 30-bit limbs (H >= 70, "tight": g*x is a Montgomery product
-//   < 2p, subtraction pads with 4 p):
-//     u < 2 ; x' < 6 ; squarings of x', y' have A B = 36 <= H ; t < 2 ; y' < 6 ; x'' < 6 + 2 + 1 = 9
-//   BLS12-381 on 30-bit limbs (H = 630, g = 2 by limb-wise doubling, subtraction pads with 8 p):
-//     u < 4 ; x' < 10 ; A B = 100 <= H ; t < 2 ; y' < 10 ; x'' < 10 + 4 + 1 = 15
+// Loose bounds: nothing here reduces.  A Montgomery product of inputs < A p and < B p is < (A B / H + 1) p with
+// H = R'/p, a subtraction adds the pad (kSubK p: 8 p for BLS12-381 on 30-bit limbs, 64 p on 29-bit limbs of the
+// 381/377-bit fields, 4 p for the "tight" layouts whose g * x is a product), and the caller settles x and y once per
+// round after the linear layer.  What every statement below meets -- largest operands, largest result, share of its
+// limit, for every field and every kernel that inlines it -- is in BOUNDS.md next to this file: generated by walking
+// THIS code over a bound-carrying arithmetic (tests/cpp/bounds_walk, tools/bounds_walk.py) and checked by
+// tests/test_bounds_walk.py, which fails when a pad, a limb count, a schedule or the order of two statements here
+// breaks a precondition.  Orders of magnitude (lane-private layouts): the S-box input x' is < 9.1 p on BLS12-381
+// (limit of the 30-bit assembly: 16 p), < 5.3 p on the tight fields (A B = 27 of H = 70.7 on Jubjub); every
+// subtrahend is a product or g times one (<= 2.0x p, pads 4 p / 8 p).
 template <class F, class A, int WIN, bool USEX = true>
 __device__ __forceinline__ void flystel(typename A::Fe& x, typename A::Fe& y, const PermConsts& pc,
                                         const LdsTable<A>& tab) {
@@ -229,14 +238,10 @@ __device__ __forceinline__ void flystel(typename A::Fe& x, typename A::Fe& y, co
   A::add_delta(x, x);
 }
 
-// Linear layer (src/traits.rs:136-157).
-// Loose bounds, big-H fields: W=2 entering < 98: y < 196, x < 294.  W=4, g <= 15, entering < 98:
-// x0 < 98+15*98 = 1568, x1 < 98+15*1568 < 2^15, same for y; after the PHT step < 2^17 -- additions
-// only, then settle() (valid for inputs < H p = 2^25 p).
-// Tight fields, entering < 10: W=2: y < 17+.., x < 27 -> settle (27/70 + 1 < 2).  W=4: g*x < 2, so
-// x0, x1 < 12, y2, y3 < 9, PHT: < 21, < 33 -> settle (33/70 + 1 < 2); all values < 2^261.
-// BLS12-381 on 30-bit limbs, entering < 16: W=2: y < 27, x < 43.  W=4 (g = 2): x0 < 48, x1 < 112, same
-// for y, PHT: < 224, < 336 -> settle (336 <= H = 630; 336 p < 2^390).
+// Linear layer (src/traits.rs:136-157): additions only (g * x by limb scaling or as a product, mont29.h), then ONE
+// settle per state element -- valid while the sums stay below H p, and below R' as limb vectors.  Largest sums
+// (BOUNDS.md, walked): W = 2: < 21 p on Jubjub (H = 70.7), < 35 p on BLS12-381 (H = 630); W = 4: < 24.5 p on the
+// 9-limb fields, < 240 p on BLS12-381 (g = 2 by doubling: 85.5 p + 153.2 p in the last PHT addition) -- 38 % of R' at most.
 template <class F, class A, int W>
 __device__ __forceinline__ void mds_layer(typename A::Fe (&st)[W]) {
   if (W == 2) {

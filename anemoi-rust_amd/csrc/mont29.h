@@ -11,7 +11,8 @@
 // The spare bits also remove every conditional subtraction: with H = R'/p (R' = 2^(29*NL); 2^25 for
 // the 381/377-bit fields, 70..438 for the 253..255-bit ones) a Montgomery product of inputs < A p
 // and < B p is < (A B / H + 1) p, so additions / subtractions need no reduction at all and values
-// are made canonical once, on the way out.  The bounds are tracked in anemoi_perm.h.
+// are made canonical once, on the way out.  The bounds every statement of every kernel meets are walked on the
+// kernels' own code and listed in BOUNDS.md (tests/cpp/bounds_walk, tools/bounds_walk.py, tests/test_bounds_walk.py).
 //
 // Element form inside the kernels: NL limbs l[i] < 2^29, value = sum l[i] 2^(29 i), Montgomery form
 // with R' = 2^(29 NL).  The C-ABI form (arkworks: 32-bit-limb R = 2^(64 L)) is converted on load
@@ -162,7 +163,7 @@ struct Arith29 {
     acc >>= W;
   }
 
-  // r = a + b (no reduction; the caller keeps values < 2^12 p, see anemoi_perm.h)
+  // r = a + b (no reduction; the sum must stay below R' = 2^(W NL): the walk of tests/test_bounds_walk.py checks every call)
   __device__ static __forceinline__ void add(Fe& r, const Fe& a, const Fe& b) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + b.l[i];
@@ -176,8 +177,8 @@ struct Arith29 {
     norm(r);
   }
 
-  // r = a - b + kSubK29*p >= 0  (b < ~60 p): KP29 is kSubK29*p with limbs padded to >= 2^29, so no
-  // limb goes negative
+  // r = a - b + kSubK p >= 0: KP is kSubK p with its lower limbs padded to >= 2^W - 1 (tools/gen_params.py), so no limb
+  // goes negative while b's TOP limb stays <= KP's (b < kSubK p, a hair less); every call is checked by the bounds walk
   __device__ static __forceinline__ void sub(Fe& r, const Fe& a, const Fe& b) {
 #pragma unroll
     for (int i = 0; i < NL; i++) r.l[i] = a.l[i] + L::KP[i] - b.l[i];

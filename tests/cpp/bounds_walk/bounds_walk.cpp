@@ -1,0 +1,821 @@
+// bounds_walk.cpp -- the KERNEL BODIES of anemoi-rust_amd/csrc, compiled for the host over arithmetics that carry an
+// UPPER BOUND of every value instead of the value (g++ -DANEMOI_BOUNDS_WALK, the HIP vocabulary from ./hip/hip_runtime.h).
+//
+// Why: the lane-private arithmetic (mont29.h) never reduces inside a round, and neither do the cooperative ones
+// (coop29.h, coop2d.h); bit-exactness of the headline kernel and of every other kernel rests on each value staying
+// below what its consumer tolerates (H p for a product that must end below 2p, the pad for a subtrahend, R' for a limb
+// vector).  Those bounds used to live in comments.  Here the very templates the GPU kernels are made of -- permutation,
+// flystel, mds_layer, mds_pair, mds_cols, the sponge absorb loops and their segment carry, the path climb, the Jive
+// feed-forward, the ABI conversions, coop_permutation / coop_flystel -- run as ordinary C++ with
+//      ArithFor<FIELD>          = BoundsWalkArith   (the interface of Arith29)
+//      CoopArith<F, LPI>::type  = BoundsWalkCoop    (the interface of Coop29 / Coop2d)
+// An element is an id into a table of exact integers (the largest value it can hold); every A::mul / sqr / add / sub /
+// mul_g / settle / from_abi / to_abi ... computes the result's bound from its operands' and is logged with the
+// file:line of the statement that called it.  This program only PROPAGATES; tests/test_bounds_walk.py is the judge: it
+// re-derives every distinct step with Python integers from the constants of tests/golden/params.json and checks the
+// preconditions (product inputs inside the generated assembly's documented limits, subtrahends under the pad limb by
+// limb, sums below R', conversions ending below 2p).  Reordering two statements of a kernel, changing a pad, a limb
+// count or an exponent schedule changes what is logged, and the judge sees it.
+//
+// One coroutine per emulated lane (1 for the lane-private kernels, 2 for the lane-pair kernels, NUM_COLUMNS for the
+// run-time-instance kernels, one per COLUMN for the cooperative kernels, whose lanes hold limbs of one value); the
+// cross-lane operations the kernels use between values (DPP quad_perm, __shfl, __shfl_xor) rendezvous and pass the ids.
+//
+//     make -C tests/cpp/bounds_walk -j8 && tests/cpp/build/bounds_walk_<field> <out.txt>      (one program per field)
+#include <hip/hip_runtime.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <map>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+WalkDim3 threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, gridDim{1, 1, 1};
+
+// ---- exact unsigned integers (1 024 bits: a product of two bounds below 2^430 and room to spare) ---------------------
+struct Big {
+  static constexpr int N = 16;
+  uint64_t w[N];
+  static bool& overflowed() {
+    static bool f = false;
+    return f;
+  }
+  Big(uint64_t v = 0) {
+    for (int i = 0; i < N; i++) w[i] = 0;
+    w[0] = v;
+  }
+  static Big pow2(int bits) {
+    Big r;
+    r.w[bits / 64] = 1ull << (bits % 64);
+    return r;
+  }
+  static Big from_limbs(const uint32_t* l, int nl, int W) {
+    Big r;
+    for (int i = nl - 1; i >= 0; i--) r = r.shl(W) + Big(l[i]);
+    return r;
+  }
+  friend Big operator+(const Big& a, const Big& b) {
+    Big r;
+    unsigned __int128 c = 0;
+    for (int i = 0; i < N; i++) {
+      c += (unsigned __int128)a.w[i] + b.w[i];
+      r.w[i] = (uint64_t)c;
+      c >>= 64;
+    }
+    if (c) overflowed() = true;
+    return r;
+  }
+  friend Big operator-(const Big& a, const Big& b) {   // a >= b
+    Big r;
+    unsigned __int128 bw = 0;
+    for (int i = 0; i < N; i++) {
+      const unsigned __int128 d = (unsigned __int128)a.w[i] - b.w[i] - bw;
+      r.w[i] = (uint64_t)d;
+      bw = (d >> 64) & 1;
+    }
+    if (bw) overflowed() = true;
+    return r;
+  }
+  friend Big operator*(const Big& a, const Big& b) {
+    Big r;
+    for (int i = 0; i < N; i++) {
+      if (!a.w[i]) continue;
+      unsigned __int128 c = 0;
+      for (int j = 0; j < N; j++) {
+        if (i + j >= N) {
+          if (b.w[j] || c) overflowed() = true;
+          break;
+        }
+        c += (unsigned __int128)a.w[i] * b.w[j] + r.w[i + j];
+        r.w[i + j] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+    return r;
+  }
+  Big shl(int bits) const {
+    Big r;
+    const int q = bits / 64, s = bits % 64;
+    for (int i = N - 1; i >= 0; i--) {
+      uint64_t v = 0;
+      if (i - q >= 0) v = w[i - q] << s;
+      if (s && i - q - 1 >= 0) v |= w[i - q - 1] >> (64 - s);
+      r.w[i] = v;
+    }
+    for (int i = N - q; i < N; i++)
+      if (i >= 0 && w[i]) overflowed() = true;
+    return r;
+  }
+  Big shr(int bits) const {
+    Big r;
+    const int q = bits / 64, s = bits % 64;
+    for (int i = 0; i < N; i++) {
+      uint64_t v = 0;
+      if (i + q < N) v = w[i + q] >> s;
+      if (s && i + q + 1 < N) v |= w[i + q + 1] << (64 - s);
+      r.w[i] = v;
+    }
+    return r;
+  }
+  friend bool operator<(const Big& a, const Big& b) {
+    for (int i = N - 1; i >= 0; i--)
+      if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
+    return false;
+  }
+  friend bool operator==(const Big& a, const Big& b) { return !(a < b) && !(b < a); }
+  std::string hex() const {
+    char buf[20];
+    std::string s;
+    bool lead = true;
+    for (int i = N - 1; i >= 0; i--) {
+      if (lead && !w[i] && i) continue;
+      snprintf(buf, sizeof buf, lead ? "%llx" : "%016llx", (unsigned long long)w[i]);
+      s += buf;
+      lead = false;
+    }
+    return s;
+  }
+};
+static Big bmax(const Big& a, const Big& b) { return a < b ? b : a; }
+// A bound rounded UP to 24 significant bits is still a bound (2^-23 looser), and it makes the steps of different
+// rounds -- whose exact bounds differ in the low bits of their round constants -- the same step.
+static Big round_up(const Big& v) {
+  int top = -1;
+  for (int i = Big::N - 1; i >= 0 && top < 0; i--)
+    if (v.w[i]) top = 64 * i + 63 - __builtin_clzll(v.w[i]);
+  if (top < 24) return v;
+  const int drop = top - 23;
+  const Big hi = v.shr(drop);
+  if (hi.shl(drop) == v) return v;
+  return (hi + Big(1)).shl(drop);
+}
+
+namespace walk {
+
+// ---- the lane scheduler: coroutines, switched only at the cross-lane operations ------------------------------------------
+struct Lane {
+  ucontext_t ctx;
+  int id = 0;
+  bool done = false;
+};
+static std::vector<Lane> g_lane;
+constexpr size_t kStackBytes = 4u << 20;
+static char* lane_stack(size_t i) {   // allocated once, reused by every case
+  static std::vector<char*> pool;
+  while (pool.size() <= i) pool.push_back((char*)malloc(kStackBytes));
+  return pool[i];
+}
+static int g_cur = 0, g_active = 1, g_count = 0;
+static unsigned g_gen = 0;
+static ucontext_t g_main;
+static const std::function<void()>* g_body = nullptr;
+static uint32_t g_slot[64];
+
+static void yield() { swapcontext(&g_lane[g_cur].ctx, &g_main); }
+
+void barrier() {
+  if (g_lane.size() <= 1) return;
+  const unsigned gen = g_gen;
+  if (++g_count == g_active) {
+    g_count = 0;
+    g_gen++;
+  } else {
+    while (g_gen == gen) yield();
+  }
+}
+
+uint32_t exchange(uint32_t mine, int src_lane) {
+  if (g_lane.size() <= 1) return mine;
+  g_slot[threadIdx.x & 63] = mine;
+  barrier();
+  uint32_t got = mine;
+  for (const Lane& l : g_lane)
+    if (l.id == src_lane) got = g_slot[src_lane & 63];
+  barrier();
+  return got;
+}
+
+static void trampoline() {
+  (*g_body)();
+  g_lane[g_cur].done = true;
+  swapcontext(&g_lane[g_cur].ctx, &g_main);
+}
+
+// run `body` once per emulated lane (the given threadIdx.x values), in lockstep at the cross-lane operations
+static void run_lanes(const std::vector<int>& ids, const std::function<void()>& body) {
+  g_lane.clear();
+  g_lane.resize(ids.size());
+  g_body = &body;
+  g_count = 0;
+  g_active = int(ids.size());
+  for (size_t i = 0; i < ids.size(); i++) {
+    Lane& l = g_lane[i];
+    l.id = ids[i];
+    getcontext(&l.ctx);
+    l.ctx.uc_stack.ss_sp = lane_stack(i);
+    l.ctx.uc_stack.ss_size = kStackBytes;
+    l.ctx.uc_link = &g_main;
+    makecontext(&l.ctx, trampoline, 0);
+  }
+  for (;;) {
+    bool any = false, progress = false;
+    const unsigned gen = g_gen;
+    for (size_t i = 0; i < g_lane.size(); i++) {
+      if (g_lane[i].done) continue;
+      any = true;
+      g_cur = int(i);
+      threadIdx = WalkDim3{unsigned(g_lane[i].id), 0, 0};
+      swapcontext(&g_main, &g_lane[i].ctx);
+      if (g_lane[i].done) progress = true;
+    }
+    if (!any) break;
+    if (g_gen != gen) progress = true;
+    if (!progress) {
+      fprintf(stderr, "bounds_walk: the emulated lanes fell out of lockstep (a lane-dependent branch around a cross-lane operation)\n");
+      abort();
+    }
+  }
+  threadIdx = WalkDim3{0, 0, 0};
+  g_lane.clear();
+}
+static void run_lanes(int n, const std::function<void()>& body) {
+  std::vector<int> ids;
+  for (int i = 0; i < n; i++) ids.push_back(i);
+  run_lanes(ids, body);
+}
+
+// ---- the log ------------------------------------------------------------------------------------------------------------
+static FILE* g_out = nullptr;
+static std::string g_case, g_arith;
+static int g_field = 0;
+static std::vector<Big> g_val;
+constexpr uint32_t kTag = 0xC0000000u, kTagMask = 0xF0000000u;   // limbs are < 2^31: an id never looks like a limb
+
+struct SiteStat {
+  unsigned long n = 0;
+  Big a, b, out;
+  std::string where;
+};
+typedef std::tuple<int, std::string, std::string, int, std::string> SiteKey;   // field, arith, file, line, op
+static std::map<SiteKey, SiteStat> g_site;
+struct StepStat {
+  unsigned long n = 0;
+  std::string first, text;
+};
+static std::unordered_map<std::string, StepStat> g_step;   // field, arith, op and the three integers, as bytes
+
+static const char* base_name(const char* f) {
+  const char* b = f;
+  for (const char* p = f; *p; p++)
+    if (*p == '/') b = p + 1;
+  return b;
+}
+
+static void key_bytes(std::string& k, const Big& v) {
+  int top = Big::N - 1;
+  while (top > 0 && !v.w[top]) top--;
+  k.push_back(char(top));
+  k.append((const char*)v.w, size_t(top + 1) * 8);
+}
+
+// logs one operation; the value kept for the result is its bound rounded up (round_up above)
+static uint32_t log_op(const char* op, const char* file, int line, const Big& a, const Big& b, const Big& exact_out) {
+  // (a walk that has left every limit -- a mutated build -- is held at 2^500, above any R', so that the integers stay inside
+  // their 1 024 bits; the judge rejects the step that got there)
+  const Big out = Big::pow2(500) < exact_out ? Big::pow2(500) : round_up(exact_out);
+  SiteStat& s = g_site[SiteKey(g_field, g_arith, base_name(file), line, op)];
+  if (s.n == 0 || s.out < out) s.where = g_case;
+  s.n++;
+  s.a = bmax(s.a, a), s.b = bmax(s.b, b), s.out = bmax(s.out, out);
+  std::string k;
+  k.push_back(char(g_field));
+  k += g_arith;
+  k += op;
+  key_bytes(k, a), key_bytes(k, b), key_bytes(k, out);
+  StepStat& t = g_step[k];
+  if (t.n++ == 0) {
+    t.first = g_case + "|" + base_name(file) + ":" + std::to_string(line);
+    t.text = std::to_string(g_field) + " " + g_arith + " " + op + " " + a.hex() + " " + b.hex() + " " + out.hex();
+  }
+  g_val.push_back(out);
+  return uint32_t(g_val.size() - 1);
+}
+
+static std::vector<std::string> g_cases;
+static void begin_case(const std::string& name, int field, const char* arith) {
+  g_cases.push_back(std::string(arith) + " " + name);
+  g_case = name;
+  g_field = field;
+  g_arith = arith;
+  g_val.clear();
+}
+
+static const Big& value(uint32_t id) {
+  if (id >= g_val.size()) {
+    fprintf(stderr, "bounds_walk: a value id from another case (%s)\n", g_case.c_str());
+    abort();
+  }
+  return g_val[id];
+}
+
+static void dump() {
+  for (auto& c : g_cases) fprintf(g_out, "case %s\n", c.c_str());
+  for (auto& kv : g_site)
+    fprintf(g_out, "site %d %s %s:%d %s n=%lu a=%s b=%s out=%s in=%s\n", std::get<0>(kv.first), std::get<1>(kv.first).c_str(),
+            std::get<2>(kv.first).c_str(), std::get<3>(kv.first), std::get<4>(kv.first).c_str(), kv.second.n, kv.second.a.hex().c_str(),
+            kv.second.b.hex().c_str(), kv.second.out.hex().c_str(), kv.second.where.c_str());
+  std::vector<std::string> lines;
+  for (auto& kv : g_step) lines.push_back("step " + kv.second.text + " n=" + std::to_string(kv.second.n) + " first=" + kv.second.first);
+  std::sort(lines.begin(), lines.end());
+  for (auto& l : lines) fprintf(g_out, "%s\n", l.c_str());
+}
+
+}  // namespace walk
+
+#include "anemoi_kernels.h"
+
+namespace anemoi {
+
+uint4 lds[1 << 16];   // the kernels' `extern __shared__ uint4 lds[]`
+
+// what a limb layout (F::Lane, F::Coop, F::Fold) says about its field, as exact integers
+template <class F, class L>
+struct LayoutInfo {
+  Big p, R, KP, One, In, Out, RR, GMont, Delta;
+  LayoutInfo() {
+    p = Big::from_limbs(L::P, L::NL, L::W);
+    R = Big::pow2(L::W * L::NL);
+    KP = Big::from_limbs(L::KP, L::NL, L::W);
+    One = Big::from_limbs(L::One, L::NL, L::W);
+    In = Big::from_limbs(L::In, L::NL, L::W);
+    Out = Big::from_limbs(L::Out, L::NL, L::W);
+    RR = Big::from_limbs(L::RR, L::NL, L::W);
+    GMont = Big::from_limbs(L::GMont, L::NL, L::W);
+    Delta = Big::from_limbs(L::Delta, L::NL, L::W);
+  }
+  static const LayoutInfo& get() {
+    static const LayoutInfo i;
+    return i;
+  }
+  // Montgomery product, digit-serial (mont29.h, coop29.h, coop2d.h's mul_exact): (a b + m p) / R' with m <= R' - 1
+  Big mont(const Big& a, const Big& b) const { return (a * b + (R - Big(1)) * p).shr(L::W * L::NL); }
+  Big chunk_max() const { return Big::pow2(8 * F::kChunk) - Big(1); }   // chunk_to_fe: kChunk bytes, or fewer and a 0x01
+};
+
+#define WALK_SITE const char *file = __builtin_FILE(), int line = __builtin_LINE()
+
+// The interface of Arith29 (mont29.h).  Fe::l[0] carries the value id (tagged); an Fe whose l[0] is NOT tagged was
+// written limb by limb outside the arithmetic and is taken at the value its limbs spell.
+template <class F>
+struct BoundsWalkArith {
+  using L = typename F::Lane;
+  using Info = LayoutInfo<F, L>;
+  static constexpr int W = L::W, NL = L::NL, NABI = F::N, NQ = (NL + 3) / 4;
+  static constexpr uint32_t MASK = (1u << W) - 1;
+  static constexpr bool kLoose = true;
+  static constexpr bool kTight = L::kTight;
+  struct Fe {
+    uint32_t l[NL];
+  };
+  static const Big zero() { return Big(0); }
+  static Big val(const Fe& v, const char* file, int line) {
+    if ((v.l[0] & walk::kTagMask) == walk::kTag) return walk::value(v.l[0] & ~walk::kTagMask);
+    const Big raw = Big::from_limbs(v.l, NL, W);
+    walk::log_op("raw", file, line, raw, zero(), raw);
+    return raw;
+  }
+  static void set(Fe& r, uint32_t id) {
+    for (int i = 0; i < NL; i++) r.l[i] = 0;
+    r.l[0] = walk::kTag | id;
+  }
+  static void mul(Fe& r, const Fe& a, const Fe& b, WALK_SITE) {
+    const Big x = val(a, file, line), y = val(b, file, line);
+    set(r, walk::log_op("mul", file, line, x, y, Info::get().mont(x, y)));
+  }
+  static void sqr(Fe& r, const Fe& a, WALK_SITE) {
+    const Big x = val(a, file, line);
+    set(r, walk::log_op("sqr", file, line, x, x, Info::get().mont(x, x)));
+  }
+  static void emul(Fe& r, const Fe& a, const Fe& b, WALK_SITE) { mul(r, a, b, file, line); }
+  static void esqr(Fe& r, const Fe& a, WALK_SITE) { sqr(r, a, file, line); }
+  static void efinish(Fe&) {}
+  static void add(Fe& r, const Fe& a, const Fe& b, WALK_SITE) {
+    const Big x = val(a, file, line), y = val(b, file, line);
+    set(r, walk::log_op("add", file, line, x, y, x + y));
+  }
+  static void add_k(Fe& r, const Fe& a, const uint32_t* k, WALK_SITE) {
+    const Big x = val(a, file, line), y = Big::from_limbs(k, NL, W);
+    set(r, walk::log_op("add_k", file, line, x, y, x + y));
+  }
+  static void sub(Fe& r, const Fe& a, const Fe& b, WALK_SITE) {
+    const Big x = val(a, file, line), y = val(b, file, line);
+    set(r, walk::log_op("sub", file, line, x, y, x + Info::get().KP));
+  }
+  static void mul_g(Fe& r, const Fe& a, WALK_SITE) {
+    const Big x = val(a, file, line);
+    if (kTight) set(r, walk::log_op("mul_g_product", file, line, x, Info::get().GMont, Info::get().mont(x, Info::get().GMont)));
+    else set(r, walk::log_op("mul_g_scale", file, line, x, Big(F::kG), x * Big(F::kG)));
+  }
+  static void settle(Fe& a, WALK_SITE) {
+#ifdef WALK_MUTATE_NO_SETTLE   // tests/test_bounds_walk.py: "somebody removed the settle" must turn the judge red
+    (void)file, (void)line, (void)a;
+    return;
+#endif
+    const Big x = val(a, file, line);
+    set(a, walk::log_op("settle", file, line, x, Info::get().One, Info::get().mont(x, Info::get().One)));
+  }
+  static void set_one(Fe& x, WALK_SITE) { set(x, walk::log_op("one", file, line, zero(), zero(), Info::get().One)); }
+  static void set_zero(Fe& x, WALK_SITE) { set(x, walk::log_op("zero", file, line, zero(), zero(), zero())); }
+  static void add_delta(Fe& r, const Fe& a, WALK_SITE) { add_k(r, a, L::Delta, file, line); }
+  // the words are whatever the staging area holds; the contract is "a fully reduced ABI element" (include/anemoi_mi355x.h)
+  static void from_abi(Fe& r, const uint32_t (&)[NABI], WALK_SITE) {
+    const Info& I = Info::get();
+    const Big x = I.p - Big(1);
+    set(r, walk::log_op("from_abi", file, line, x, I.In, I.mont(x, I.In)));
+  }
+  static void to_abi(uint32_t (&w)[NABI], const Fe& a, WALK_SITE) {
+    const Info& I = Info::get();
+    const Big x = val(a, file, line);
+    walk::log_op("to_abi", file, line, x, I.Out, I.mont(x, I.Out));   // then canonical(): the judge wants this below 2p
+    for (int i = 0; i < NABI; i++) w[i] = 0;
+  }
+  static void from_int(Fe& r, const uint32_t (&)[NABI], WALK_SITE) {
+    const Info& I = Info::get();
+    const Big x = I.chunk_max();
+    set(r, walk::log_op("from_int", file, line, x, I.RR, I.mont(x, I.RR)));
+  }
+  // the window table: the id travels through the kernels' LDS layout
+  static void lds_store(uint4* base, int, const Fe& v) {
+    if ((v.l[0] & walk::kTagMask) != walk::kTag) abort();
+    base[0].x = v.l[0];
+  }
+  static void lds_load(const uint4* base, int, Fe& v) {
+    if ((base[0].x & walk::kTagMask) != walk::kTag) {
+      fprintf(stderr, "bounds_walk: window-table entry read before it was written (%s)\n", walk::g_case.c_str());
+      abort();
+    }
+    set(v, base[0].x & ~walk::kTagMask);
+  }
+  static const uint32_t* host_ark(int width, bool d) {
+    return width == 2 ? (d ? L::ArkD_21 : L::ArkC_21) : (d ? L::ArkD_43 : L::ArkC_43);
+  }
+};
+
+// The interface of Coop29 (LPI = 16: the scan, layout F::Coop) and of Coop2d<F, 2> (LPI = 32: the two-row fold, layout
+// F::Fold).  A value lives on the lanes of its row / row pair, one limb each; the walk emulates ONE lane per value
+// (limb 0), whose register carries the tagged id.  Round constants arrive as limb 0 of the tables in PermConsts: the
+// walk's tables hold tagged ids of constants it registered.
+template <class F, int LPI>
+struct BoundsWalkCoop {
+  static constexpr bool kFold = LPI == 32;
+  using L = std::conditional_t<kFold, typename F::Fold, typename F::Coop>;
+  using Info = LayoutInfo<F, L>;
+  static constexpr int NL = L::NL, W = L::W, NABI = F::N, kLanesPerItem = LPI;
+  static constexpr uint32_t MASK = (1u << W) - 1;
+  struct K {
+    uint32_t delta, one;
+  };
+  static uint32_t limb() { return threadIdx.x & 15u; }
+  static bool writer() { return true; }
+  static const char* op_suffix() { return ""; }
+  static Big val(uint32_t v, const char* file, int line) {
+    if ((v & walk::kTagMask) == walk::kTag) return walk::value(v & ~walk::kTagMask);
+    if (v != 0) {
+      fprintf(stderr, "bounds_walk: an untagged non-zero register in %s at %s:%d\n", walk::g_case.c_str(), file, line);
+      abort();
+    }
+    return Big(0);   // `uint32_t x = 0, y = 0`: the zero state of a sponge
+  }
+  static uint32_t tag(uint32_t id) { return walk::kTag | id; }
+  // the fold product ends below a b / R' + (NL (2^W + 32) + 2) p  (tools/coop2d_model.py, tests/test_coop2d_model.py)
+  static Big product(const Big& a, const Big& b) {
+    const Info& I = Info::get();
+    if (!kFold) return I.mont(a, b);
+    return (a * b).shr(W * NL) + Big(uint64_t(NL) * ((1ull << W) + 32) + 2) * I.p;
+  }
+  static uint32_t konst(const char* name, const Big& v, const char* file, int line) {
+    return tag(walk::log_op(name, file, line, Big(0), Big(0), v));
+  }
+  static K load_consts(WALK_SITE) {
+    const Info& I = Info::get();
+    return K{konst("delta", I.Delta, file, line), konst("one", I.One, file, line)};
+  }
+  static uint32_t mul(uint32_t a, uint32_t b, const K&, WALK_SITE) {
+    const Big x = val(a, file, line), y = val(b, file, line);
+    return tag(walk::log_op("mul", file, line, x, y, product(x, y)));
+  }
+  static uint32_t sqr_n(uint32_t a, uint32_t n, const K& k, WALK_SITE) {
+    for (uint32_t i = 0; i < n; i++) a = mul(a, a, k, file, line);
+    return a;
+  }
+  static uint32_t sqr_mul(uint32_t a, uint32_t n, uint32_t b, const K& k, WALK_SITE) {
+    return mul(sqr_n(a, n, k, file, line), b, k, file, line);
+  }
+  static uint32_t add(uint32_t a, uint32_t b, WALK_SITE) {
+    const Big x = val(a, file, line), y = val(b, file, line);
+    return tag(walk::log_op("add", file, line, x, y, x + y));
+  }
+  static uint32_t sub(uint32_t a, uint32_t b, const K&, WALK_SITE) {
+    const Big x = val(a, file, line), y = val(b, file, line);
+    return tag(walk::log_op("sub", file, line, x, y, x + Info::get().KP));
+  }
+  static constexpr bool scale_g() {
+    if constexpr (kFold) return L::kScaleG;
+    else return !L::kTight;
+  }
+  static uint32_t mul_g(uint32_t a, const K&, WALK_SITE) {
+    const Info& I = Info::get();
+    const Big x = val(a, file, line);
+    if (scale_g()) return tag(walk::log_op("mul_g_scale", file, line, x, Big(F::kG), x * Big(F::kG)));
+    return tag(walk::log_op("mul_g_product", file, line, x, I.GMont, product(x, I.GMont)));
+  }
+  static uint32_t mul_g_settled(uint32_t a, const K& k, WALK_SITE) {
+    if (!kFold) return mul_g(a, k, file, line);   // coop29.h: the same function
+    const Info& I = Info::get();
+    const Big x = val(a, file, line);
+    return tag(walk::log_op("mul_g_product", file, line, x, I.GMont, product(x, I.GMont)));
+  }
+  static uint32_t settle(uint32_t a, const K&, WALK_SITE) {
+    const Info& I = Info::get();
+    const Big x = val(a, file, line);
+    return tag(walk::log_op("settle", file, line, x, I.One, product(x, I.One)));
+  }
+  static uint32_t from_abi(uint32_t, const K&, WALK_SITE) {
+    const Info& I = Info::get();
+    const Big x = I.p - Big(1);
+    return tag(walk::log_op("from_abi", file, line, x, I.In, product(x, I.In)));
+  }
+  static uint32_t to_mont(uint32_t, const K&, WALK_SITE) {   // a chunk of a byte message (k_sponge_coop)
+    const Info& I = Info::get();
+    const Big x = I.chunk_max();
+    return tag(walk::log_op("from_int", file, line, x, I.RR, product(x, I.RR)));
+  }
+  static uint32_t to_abi(uint32_t a, const K&, WALK_SITE) {   // both arithmetics convert with the digit-serial product
+    const Info& I = Info::get();
+    const Big x = val(a, file, line);
+    walk::log_op("to_abi", file, line, x, I.Out, I.mont(x, I.Out));
+    return 0;
+  }
+};
+
+// the two-row fold kernels read their round constants from pc.fold_c / pc.fold_d (anemoi_coop_kernels.h)
+template <class F>
+struct CoopArk<BoundsWalkCoop<F, 32>> {
+  static const uint32_t* c(const PermConsts& pc) { return pc.fold_c; }
+  static const uint32_t* d(const PermConsts& pc) { return pc.fold_d; }
+};
+#undef WALK_SITE
+
+}  // namespace anemoi
+
+using namespace anemoi;
+
+// ---- per-field drivers ------------------------------------------------------------------------------------------------
+template <int FIELD>
+struct Walk {
+  using F = FieldC<FIELD>;
+  using A = ArithFor<FIELD>;
+  static constexpr int WIN = KernelCfg<F::N>::WIN;
+
+  std::vector<uint32_t> sched, sched_plain, sched5, coop_c, coop_d, fold_c, fold_d;
+  PermConsts pc{};
+  int width;
+
+  static std::vector<uint32_t> words(const uint8_t* s, int steps) {   // (squarings | op << 8), as runtime.h uploads them
+    std::vector<uint32_t> w;
+    for (int i = 0; i < steps; i++) w.push_back(uint32_t(s[2 * i]) | (uint32_t(s[2 * i + 1]) << 8));
+    w.push_back(0xff00), w.push_back(0xff00);   // the two words past the end that the pipelined loops prefetch
+    return w;
+  }
+
+  explicit Walk(int width_) : width(width_) {
+    static_assert(WIN == 3, "the shipped window");
+    sched_plain = words(F::kW3Sched, F::kW3Steps);
+    pc.sched_plain = sched_plain.data(), pc.steps_plain = F::kW3Steps, pc.first_plain = F::kW3First;
+    if (F::kXDigits > 0 && ANEMOI_XDIGITS_ON) {
+      sched = words(F::kXSched, F::kXSteps);
+      pc.sched = sched.data(), pc.steps = F::kXSteps, pc.first = F::kXFirst;
+    } else {
+      pc.sched = pc.sched_plain, pc.steps = pc.steps_plain, pc.first = pc.first_plain;
+    }
+    if (F::kCoopWin == 5) sched5 = words(F::kW5Sched, F::kW5Steps), pc.steps5 = F::kW5Steps, pc.first5 = F::kW5First;
+    else if (F::kCoopWin == 4) sched5 = words(F::kW4Sched, F::kW4Steps), pc.steps5 = F::kW4Steps, pc.first5 = F::kW4First;
+    else if (F::kCoopWin == 3) sched5 = words(F::kW3Sched, F::kW3Steps), pc.steps5 = F::kW3Steps, pc.first5 = F::kW3First;
+    else sched5 = words(F::kW2Sched, F::kW2Steps), pc.steps5 = F::kW2Steps, pc.first5 = F::kW2First;
+    pc.sched5 = sched5.data();
+    pc.ark_c = A::host_ark(width, false);
+    pc.ark_d = A::host_ark(width, true);
+    pc.simds = 1024;
+  }
+
+  // the cooperative kernels' round-constant tables for THIS case: limb 0 of every constant replaced by the tagged id of a
+  // constant registered with its exact value (the kernels read one limb per lane; the walk's lane is limb 0)
+  template <class L>
+  void tag_table(std::vector<uint32_t>& dst, const uint32_t* src, int count, const char* name) {
+    dst.assign(src, src + size_t(count) * L::NL);
+    for (int i = 0; i < count; i++) {
+      const Big v = Big::from_limbs(src + size_t(i) * L::NL, L::NL, L::W);
+      dst[size_t(i) * L::NL] = walk::kTag | walk::log_op(name, "field_consts_gen.h", 0, Big(0), Big(0), v);
+    }
+  }
+  void coop_tables() {
+    using CL = typename F::Coop;
+    using FL = typename F::Fold;
+    const int cnt = width == 2 ? F::kRounds21 : 2 * F::kRounds43;
+    tag_table<CL>(coop_c, width == 2 ? CL::ArkC_21 : CL::ArkC_43, cnt, "ark_c");
+    tag_table<CL>(coop_d, width == 2 ? CL::ArkD_21 : CL::ArkD_43, cnt, "ark_d");
+    tag_table<FL>(fold_c, width == 2 ? FL::ArkC_21 : FL::ArkC_43, cnt, "ark_c");
+    tag_table<FL>(fold_d, width == 2 ? FL::ArkD_21 : FL::ArkD_43, cnt, "ark_d");
+    pc.coop_c = coop_c.data(), pc.coop_d = coop_d.data(), pc.fold_c = fold_c.data(), pc.fold_d = fold_d.data();
+  }
+
+  static void lane_case(const char* name, int lanes, const std::function<void()>& body) {
+    walk::begin_case(name, FIELD, "lane");
+    memset(lds, 0, sizeof(lds));
+    walk::run_lanes(lanes, body);
+  }
+  // a cooperative kernel: one emulated lane per column (W = 2: lane 0; W = 4: lanes 0 and LPI)
+  template <int LPI>
+  void coop_case(const std::string& name, const std::function<void(const PermConsts&)>& body) {
+    walk::begin_case(name, FIELD, LPI == 32 ? "fold" : "scan");
+    coop_tables();
+    const PermConsts p = pc;
+    std::vector<int> ids{0};
+    if (width == 4) ids.push_back(LPI);
+    walk::run_lanes(ids, [&] { body(p); });
+  }
+
+  static void run() {
+    std::vector<uint4> in(4096), out(4096), st(4096);
+    std::vector<uint8_t> bytes(1 << 16, 0x5a);
+    std::vector<uint64_t> index{5};
+    const size_t ch = F::kChunk;
+    // ---- Anemoi-2-1, one state per lane
+    {
+      Walk w(2);
+      const PermConsts pc = w.pc;
+      lane_case("k_permutation<2>", 1, [&] { k_permutation<FIELD, 2, false>(st.data(), 1, pc); });
+      lane_case("k_permutation<2,sbox_only>", 1, [&] { k_permutation<FIELD, 2, true>(st.data(), 1, pc); });
+      lane_case("k_jive<2,2>", 1, [&] { k_jive<FIELD, 2, 2>(in.data(), out.data(), 1, pc); });
+      lane_case("k_exp_alpha", 1, [&] { k_exp_alpha<FIELD, false>(st.data(), 1, pc); });
+      lane_case("k_exp_inv_alpha", 1, [&] { k_exp_alpha<FIELD, true>(st.data(), 1, pc); });
+      // sponge: a whole message (3 full chunks + a short one), element messages, and the two halves of a segmented run
+      for (int by = 0; by < 2; by++) {
+        const size_t len = by ? 3 * ch + 5 : 4;
+        const SpongeSeg whole{nullptr, 0, len, 1, 1};
+        std::vector<uint32_t> carry(64 * 4 * F::N, 0);
+        const SpongeSeg head{carry.data(), 0, len, 1, 0}, tail{carry.data(), 2, len, 0, 1};
+        const size_t head_len = by ? 2 * ch : 2;
+        if (by) {
+          lane_case("k_sponge<2,bytes> whole", 1, [&] { k_sponge<FIELD, 2, true>(bytes.data(), len, 1, out.data(), pc, whole); });
+          lane_case("k_sponge<2,bytes> first segment", 1, [&] { k_sponge<FIELD, 2, true>(bytes.data(), head_len, 1, out.data(), pc, head); });
+          lane_case("k_sponge<2,bytes> last segment", 1, [&] { k_sponge<FIELD, 2, true>(bytes.data(), len - head_len, 1, out.data(), pc, tail); });
+        } else {
+          lane_case("k_sponge<2,elements> whole", 1, [&] { k_sponge<FIELD, 2, false>(in.data(), len, 1, out.data(), pc, whole); });
+          lane_case("k_sponge<2,elements> first segment", 1, [&] { k_sponge<FIELD, 2, false>(in.data(), head_len, 1, out.data(), pc, head); });
+          lane_case("k_sponge<2,elements> last segment", 1, [&] { k_sponge<FIELD, 2, false>(in.data(), len - head_len, 1, out.data(), pc, tail); });
+        }
+      }
+      // ragged: two lanes, one message ends two blocks before the other (its state runs on unobserved)
+      std::vector<uint64_t> off{0, ch - 3, ch - 3 + 3 * ch};
+      lane_case("k_sponge_ragged", 2, [&] { k_sponge_ragged<FIELD>(bytes.data(), off.data(), 2, out.data(), pc); });
+      lane_case("k_merkle_climb depth 3", 1, [&] { k_merkle_climb<FIELD>(in.data(), index.data(), st.data(), 3, 1, out.data(), pc); });
+    }
+    // ---- Anemoi-4-3: a state per lane (the form no launcher uses, kept compiling) and per lane PAIR (the shipped one)
+    {
+      Walk w(4);
+      const PermConsts pc = w.pc;
+      lane_case("k_permutation<4> (one state per lane)", 1, [&] { k_permutation<FIELD, 4, false>(st.data(), 1, pc); });
+      lane_case("k_jive<4,2> (one state per lane)", 1, [&] { k_jive<FIELD, 4, 2>(in.data(), out.data(), 1, pc); });
+      lane_case("k_jive<4,4> (one state per lane)", 1, [&] { k_jive<FIELD, 4, 4>(in.data(), out.data(), 1, pc); });
+      lane_case("k_permutation_pair", 2, [&] { k_permutation_pair<FIELD, false>(st.data(), 1, pc); });
+      lane_case("k_permutation_pair<sbox_only>", 2, [&] { k_permutation_pair<FIELD, true>(st.data(), 1, pc); });
+      lane_case("k_jive_pair<2>", 2, [&] { k_jive_pair<FIELD, 2>(in.data(), out.data(), 1, pc); });
+      lane_case("k_jive_pair<4>", 2, [&] { k_jive_pair<FIELD, 4>(in.data(), out.data(), 1, pc); });
+      for (int by = 0; by < 2; by++) {
+        const size_t len = by ? 7 * ch + 5 : 7;   // 8 elements: two full rate blocks, a third with padding
+        const SpongeSeg whole{nullptr, 0, len, 1, 1};
+        std::vector<uint32_t> carry(64 * 4 * F::N, 0);
+        const SpongeSeg head{carry.data(), 0, len, 1, 0}, tail{carry.data(), 3, len, 0, 1};
+        const size_t head_len = by ? 3 * ch : 3;
+        if (by) {
+          lane_case("k_sponge_pair<bytes> whole", 2, [&] { k_sponge_pair<FIELD, true>(bytes.data(), len, 1, out.data(), pc, whole); });
+          lane_case("k_sponge_pair<bytes> first segment", 2, [&] { k_sponge_pair<FIELD, true>(bytes.data(), head_len, 1, out.data(), pc, head); });
+          lane_case("k_sponge_pair<bytes> last segment", 2, [&] { k_sponge_pair<FIELD, true>(bytes.data(), len - head_len, 1, out.data(), pc, tail); });
+        } else {
+          lane_case("k_sponge_pair<elements> whole", 2, [&] { k_sponge_pair<FIELD, false>(in.data(), len, 1, out.data(), pc, whole); });
+          lane_case("k_sponge_pair<elements> first segment", 2, [&] { k_sponge_pair<FIELD, false>(in.data(), head_len, 1, out.data(), pc, head); });
+          lane_case("k_sponge_pair<elements> last segment", 2, [&] { k_sponge_pair<FIELD, false>(in.data(), len - head_len, 1, out.data(), pc, tail); });
+        }
+      }
+      std::vector<uint64_t> off{0, 2, 2 + 9 * ch};
+      lane_case("k_sponge_ragged_pair", 4, [&] { k_sponge_ragged_pair<FIELD>(bytes.data(), off.data(), 2, out.data(), pc); });
+    }
+    // ---- instances given at run time: NUM_COLUMNS = 1 .. 16, constants through k_generic_prepare as the product does
+    {
+      Walk w(2);   // (only the exponent schedule is taken from pc)
+      const PermConsts pc = w.pc;
+      constexpr int S = generic_stride<A>(), ROUNDS = 3;
+      for (int c = 1; c <= kMaxGenericColumns; c++) {
+        std::vector<uint32_t> abi(size_t(c) * c * F::N, 0), kc(size_t(ROUNDS) * c * S), kd(kc.size()), km(size_t(c) * c * S);
+        // one case: the constants' ids must stay valid for the kernels that follow
+        walk::begin_case("run-time instance, NUM_COLUMNS = " + std::to_string(c), FIELD, "lane");
+        memset(lds, 0, sizeof(lds));
+        auto prep = [&](std::vector<uint32_t>& dst, size_t count) {
+          for (size_t i = 0; i < count; i++) walk::run_lanes(1, [&] { k_generic_prepare<FIELD>(abi.data(), dst.data() + i * S, 1); });
+        };
+        prep(kc, size_t(ROUNDS) * c), prep(kd, size_t(ROUNDS) * c), prep(km, size_t(c) * c);
+        GenericConsts gc{kc.data(), kd.data(), km.data(), c, ROUNDS};
+        std::vector<uint32_t> states(size_t(64) * 2 * c * F::N, 0), outs(states.size(), 0);
+        walk::run_lanes(c, [&] { k_permutation_cols<FIELD>(states.data(), 1, gc, pc); });
+        for (int k : {2, 2 * c})
+          if ((2 * c) % k == 0) walk::run_lanes(c, [&] { k_jive_cols<FIELD>(states.data(), outs.data(), 1, k, gc, pc); });
+        const int rate = 2 * c - 1;
+        const size_t len = size_t(rate) + 2;   // a full block, then a short one with the padding element
+        walk::run_lanes(c, [&] { k_sponge_cols<FIELD, false>(states.data(), len, 1, outs.data(), rate, gc, pc); });
+        walk::run_lanes(c, [&] { k_sponge_cols<FIELD, true>(bytes.data(), len * F::kChunk - 3, 1, outs.data(), rate, gc, pc); });
+      }
+    }
+    // ---- the latency kernels: the scan (LPI = 16) and the two-row fold (LPI = 32), both widths
+    coop_cases<16>();
+    coop_cases<32>();
+  }
+
+  template <int LPI>
+  static void coop_cases() {
+    std::vector<uint32_t> in(4096, 0), out(4096, 0), st(4096, 0);
+    std::vector<uint8_t> bytes(1 << 16, 0x5a);
+    std::vector<uint64_t> index{5};
+    const size_t ch = F::kChunk;
+    const std::string t = LPI == 32 ? "32>" : "16>";
+    {
+      Walk w(2);
+      w.template coop_case<LPI>("k_jive2_coop<" + t, [&](const PermConsts& pc) { k_jive2_coop<FIELD, LPI>(in.data(), out.data(), 1, pc); });
+      w.template coop_case<LPI>("k_permutation_coop<2," + t, [&](const PermConsts& pc) { k_permutation_coop<FIELD, 2, LPI>(st.data(), 1, pc); });
+      w.template coop_case<LPI>("k_merkle_climb_coop<" + t + " depth 3", [&](const PermConsts& pc) {
+        k_merkle_climb_coop<FIELD, LPI>(in.data(), index.data(), st.data(), 3, 1, out.data(), pc);
+      });
+      w.template coop_case<LPI>("k_sponge_coop<2,bytes," + t, [&](const PermConsts& pc) {
+        k_sponge_coop<FIELD, 2, true, LPI>(bytes.data(), 3 * ch + 5, 1, out.data(), pc);
+      });
+      w.template coop_case<LPI>("k_sponge_coop<2,elements," + t, [&](const PermConsts& pc) {
+        k_sponge_coop<FIELD, 2, false, LPI>(in.data(), 4, 1, out.data(), pc);
+      });
+    }
+    {
+      Walk w(4);
+      w.template coop_case<LPI>("k_jive4_coop<2," + t, [&](const PermConsts& pc) { k_jive4_coop<FIELD, 2, LPI>(in.data(), out.data(), 1, pc); });
+      w.template coop_case<LPI>("k_jive4_coop<4," + t, [&](const PermConsts& pc) { k_jive4_coop<FIELD, 4, LPI>(in.data(), out.data(), 1, pc); });
+      w.template coop_case<LPI>("k_permutation_coop<4," + t, [&](const PermConsts& pc) { k_permutation_coop<FIELD, 4, LPI>(st.data(), 1, pc); });
+      w.template coop_case<LPI>("k_sponge_coop<4,bytes," + t, [&](const PermConsts& pc) {
+        k_sponge_coop<FIELD, 4, true, LPI>(bytes.data(), 7 * ch + 5, 1, out.data(), pc);
+      });
+      w.template coop_case<LPI>("k_sponge_coop<4,elements," + t, [&](const PermConsts& pc) {
+        k_sponge_coop<FIELD, 4, false, LPI>(in.data(), 7, 1, out.data(), pc);
+      });
+    }
+  }
+};
+
+template <int FIELD>
+static void describe() {
+  using F = FieldC<FIELD>;
+  auto lay = [&](const char* arith, auto tagL) {
+    using L = typename decltype(tagL)::type;
+    const LayoutInfo<F, L>& I = LayoutInfo<F, L>::get();
+    fprintf(walk::g_out, "layout %d %s name=%s W=%d NL=%d g=%d chunk=%d nabi=%d p=%s KP=%s One=%s In=%s Out=%s RR=%s GMont=%s Delta=%s kp_limbs=", FIELD, arith,
+            F::kName, L::W, L::NL, F::kG, F::kChunk, F::N, I.p.hex().c_str(), I.KP.hex().c_str(), I.One.hex().c_str(), I.In.hex().c_str(),
+            I.Out.hex().c_str(), I.RR.hex().c_str(), I.GMont.hex().c_str(), I.Delta.hex().c_str());
+    for (int i = 0; i < L::NL; i++) fprintf(walk::g_out, "%s%x", i ? "," : "", L::KP[i]);
+    fputc('\n', walk::g_out);
+  };
+  lay("lane", std::common_type<typename F::Lane>{});
+  lay("scan", std::common_type<typename F::Coop>{});
+  lay("fold", std::common_type<typename F::Fold>{});
+  fprintf(walk::g_out, "flags %d lane_tight=%d scan_tight=%d fold_scale_g=%d\n", FIELD, int(F::Lane::kTight), int(F::Coop::kTight), int(F::Fold::kScaleG));
+}
+
+#ifndef WALK_FIELD
+#error "compile with -DWALK_FIELD=<field id 0..6> (tests/cpp/bounds_walk/Makefile builds one program per field)"
+#endif
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    fprintf(stderr, "usage: bounds_walk_<field> <out.txt>\n");
+    return 2;
+  }
+  walk::g_out = fopen(argv[1], "w");
+  if (!walk::g_out) return 1;
+  fprintf(walk::g_out, "walk 1 field=%d win=%d xdigits=%d\n", WALK_FIELD, ANEMOI_WIN, ANEMOI_XDIGITS_ON);
+  describe<WALK_FIELD>();
+  Walk<WALK_FIELD>::run();
+  walk::dump();
+  fprintf(walk::g_out, "overflow %d\n", int(Big::overflowed()));
+  fclose(walk::g_out);
+  return Big::overflowed() ? 3 : 0;
+}

@@ -283,9 +283,10 @@ def fold_struct(fl, p, L, g, delta, i21, i43):
         return [(v >> (W * i)) & fl.M for i in range(n)]
 
     # g * x: limb-wise while g * (2^28 + 2^6) fits 32 bits, else a product by g R'.  What the S-box subtracts is
-    # g * (a product output) or a product output; product outputs are < 2^32.5 p (tools/coop2d_bounds.py walks the
-    # permutation with exact bounds and tests/test_coop2d_model.py runs it), so the subtraction pad is the next power
-    # of two above g * 2^32.5 (or above 2^32.5), and every difference is settled (multiplied by R' mod p) at once.
+    # g * (a product output) or a product output; product outputs are < 2^32.5 p (tests/test_bounds_walk.py walks the
+    # kernels' own code with exact bounds -- anemoi-rust_amd/csrc/BOUNDS.md, "two-row fold" -- and
+    # tests/test_coop2d_model.py the model), so the subtraction pad is the next power of two above g * 2^32.5 (or above
+    # 2^32.5); x and y are settled once per round, after the linear layer.
     scale_g = g * ((1 << W) + 64) < (1 << 32)
     subk = 1 << (math.ceil(math.log2(g) + 32.5) if scale_g else 33)
     q = limbsw(subk * p)
@@ -414,7 +415,7 @@ def main():
             subk = 4 if tight else 64
             if tight and g == 2 and H >= 600:
                 # BLS12-381 on 30-bit limbs (H = 630): g*x stays a limb-wise doubling and subtraction
-                # pads with 8p -- S-box values < 15p, linear layer < 208p < H p (bounds in anemoi_perm.h)
+                # pads with 8p -- S-box values < 9.1p, linear layer < 239p < H p (walked: csrc/BOUNDS.md)
                 tight, subk = False, 8
 
             def limbsw(v, n=NL):
