@@ -351,6 +351,61 @@ def test_generated_assembly_on_the_lane_interpreter(moduli, field):
                 both_rows(r2, e, M.mul(L, want, b2[e]), ("sqr_mul", trial, n))
 
 
+@pytest.mark.parametrize("field", ["jubjub", "vesta", "bls12_381"])
+def test_same_value_operands_and_what_register_aliasing_would_do(moduli, field):
+    """`a` and `b` holding the SAME VALUE -- the leading-run doubling of Pallas / Vesta does `tmp = acc; acc =
+    sqr_mul(acc, n, tmp)` -- is fine in separate registers and WRONG if the register allocator merged them, because the
+    squaring statements rewrite %0 long before they read their last input.  The interpreter cannot see register
+    allocation, so: (i) same value, separate registers = the model; (ii) the same statement with `b` ALIASED to `a`'s
+    register gives something else (that is what a plain "+v"(a) permitted); (iii) the generator derives the need for an
+    early-clobber `a` from its own text and the committed header declares it."""
+    L = layouts(moduli)[field]
+    rng = random.Random(3)
+    nm = G.operand_names(L.NL, "sqr_mul")
+    lines = G.gen_product(L.NL, L.W, "sqr_mul")[0]
+    ct = [[(L.C[2 * q + ((lane >> 4) & 1)] >> (L.W * (lane & 15))) & L.M if (2 * q + ((lane >> 4) & 1) < L.NL and (lane & 15) < L.NL) else 0
+           for lane in range(64)] for q in range(L.Q)]
+    base = {nm["CT"][q]: ct[q] for q in range(L.Q)}
+    if L.NL > 13:
+        base[nm["MTOP"]] = [0xffffffff if (lane & 15) == 15 else L.M for lane in range(64)]
+        base[nm["ONLY15"]] = [0xffffffff if (lane & 15) == 15 else 0 for lane in range(64)]
+    a2 = operands(L, rng)[5:7]
+    for n in (1, 3):
+        want = []
+        for e in range(2):
+            w = a2[e]
+            for _ in range(n):
+                w = M.mul(L, w, w)
+            want.append(M.mul(L, w, a2[e]))
+        opnd = dict(base)
+        opnd.update({nm["A"]: wave(a2), nm["B"]: wave(a2), nm["CNT"]: n})
+        r = run_asm(lines, opnd)
+        for e in range(2):
+            assert r[2 * e * 16:(2 * e + 1) * 16] == want[e], (field, n)
+        aliased = [ln.replace(nm["B"], nm["A"]) for ln in lines]        # b lives in a's register
+        opnd = dict(base)
+        opnd.update({nm["A"]: wave(a2), nm["CNT"]: n})
+        try:
+            r = run_asm(aliased, opnd)
+        except M.Overflow:
+            r = None
+        assert r is None or r[0:16] != want[0], (field, n, "aliasing would have gone unnoticed")
+
+
+def test_early_clobber_of_the_in_out_operand():
+    text = open(os.path.join(ROOT, "anemoi-rust_amd", "csrc", "coop2d_asm_gen.h")).read()
+    for nl, W, rows in [(nl, W, r) for nl, W in G.LAYOUTS for r in ((2, 4) if nl <= 13 else (2,))]:
+        body = text[text.index("template <> struct AsmCoop2d<%d, %d, %d> {" % (nl, W, rows)):]
+        body = body[:body.index("\n};")]
+        for kind in G.KINDS:
+            lines = G.gen_product(nl, W, kind, rows)[0]
+            late = G.inputs_read_after_first_write(lines, nl, kind, rows)
+            fn = body[body.index("uint32_t %s(" % kind):]
+            outs = re.search(r'\n        : ("\+&?v"\(a\)[^\n]*)\n', fn).group(1)
+            assert (kind == "mul") == (not late), (nl, rows, kind)       # only the plain product writes its result last
+            assert outs.startswith('"+&v"(a)' if late else '"+v"(a)'), (nl, rows, kind, outs)
+
+
 @pytest.mark.parametrize("field", ["jubjub", "bn_254", "ed_on_bls12_377", "pallas"])
 def test_generated_four_row_assembly_on_the_lane_interpreter(moduli, field):
     """One element on all four rows of the wavefront (11-limb fields): multiplication, squaring runs, fused steps."""

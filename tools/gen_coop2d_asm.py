@@ -464,13 +464,40 @@ def gen_product(nl, W, kind, rows=2):
     return lines, clob, info
 
 
+def inputs_read_after_first_write(lines, nl, kind, rows=2):
+    """the input operands (b, the fold table, the masks) that an instruction still READS after the first instruction that
+    WRITES %0 -- if there is any, %0 must be an early-clobber operand"""
+    names = operand_names(nl, kind, rows)
+    inputs = [names[k] for k in ("B", "MTOP", "ONLY15") if k in names] + list(names["CT"])
+    written, late = False, set()
+    for ln in lines:
+        if ln.startswith(".") or ln.endswith(":"):
+            continue
+        op, _, rest = ln.partition(" ")
+        args = [x.strip() for x in re.split(r",\s*(?![^\[]*\])", rest)] if rest else []
+        toks = [re.split(r"\s", a)[0] for a in args]
+        if written:
+            late.update(t for t in toks[1:] if t in inputs)
+            # (a branch back into the run re-reads everything the loop body reads: bodies follow their first write)
+        if toks and toks[0] == names["A"] and not op.startswith(("s_", "v_cmp", "v_nop")):
+            written = True
+    return sorted(late)
+
+
 def render(nl, W, rows=2):
     Q = (nl + rows - 1) // rows
     out = []
     for kind in KINDS:
         lines, clob, info = gen_product(nl, W, kind, rows)
         body = "\n".join('        "%s\\n\\t"' % l for l in lines)
-        outs = ['"+v"(a)'] + (['"+s"(n)'] if kind != "mul" else [])
+        # `a` is EARLY-CLOBBER: every statement writes %0 long before it has read its last input (sqr_mul reads b in its
+        # last squaring, after the whole run has rewritten a; all of them read the fold table to the end).  Declared as a
+        # plain "+v", nothing stops the register allocator from giving `a` and an input that holds the SAME VALUE one
+        # register -- the leading-run doubling does `acc = sqr_mul(acc, n, tmp)` right after `tmp = acc` -- and the
+        # result would be silently wrong (round-4 advisor finding; inputs_read_after_first_write() derives the need
+        # from the emitted text, tests/test_coop2d_model.py pins it).
+        early = inputs_read_after_first_write(lines, nl, kind, rows)
+        outs = ['"+%sv"(a)' % ("&" if early else "")] + (['"+s"(n)'] if kind != "mul" else [])
         ins = (['"v"(b)'] if kind != "sqr_run" else []) + ['"v"(ct[%d])' % q for q in range(Q)]
         args = "uint32_t a, " + ("uint32_t b, " if kind != "sqr_run" else "") + "const uint32_t (&ct)[%d]" % Q
         if nl > 13:
