@@ -66,6 +66,8 @@ _SIGS = {
     "anemoi_num_rounds": ([_int, _int], _int),
     "anemoi_init": ([_int, _int, _int], _int),
     "anemoi_release": ([_int], _int),
+    "anemoi_warmup": ([_int, _int, _int], _int),
+    "anemoi_probe_issue_rate": ([_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)], _int),
     "anemoi_set_option": ([ctypes.c_char_p, ctypes.c_longlong], _int),
     "anemoi_get_option": ([ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)], _int),
     "anemoi_permutation_batch": ([_int, _int, _u64p, _sz, _int], _int),
@@ -138,6 +140,24 @@ def init(field, width, device=ALL_DEVICES):
         raise AnemoiError(rc, lib.anemoi_last_error().decode())
 
 
+def warmup(field, width, device=ALL_DEVICES):
+    """anemoi_init, then one small launch of every throughput kernel of (field, width) (anemoi_warmup): a service that cares
+    about the duration of its FIRST large call does this at start-up."""
+    rc = lib.anemoi_warmup(device, field_id(field), width)
+    if rc != 0:
+        raise AnemoiError(rc, lib.anemoi_last_error().decode())
+
+
+def probe_issue_rate(device=0):
+    """(lane multiply-adds per second, shader clock in GHz) of a full grid of dependent v_mad_u64_u32 chains on `device`
+    (anemoi_probe_issue_rate): what this box delivers of the instruction the throughput kernels are made of."""
+    rate, ghz = ctypes.c_double(0), ctypes.c_double(0)
+    rc = lib.anemoi_probe_issue_rate(device, ctypes.byref(rate), ctypes.byref(ghz))
+    if rc != 0:
+        raise AnemoiError(rc, lib.anemoi_last_error().decode())
+    return rate.value, ghz.value
+
+
 def release(device=ALL_DEVICES):
     """Free everything the library holds on `device` (anemoi_release); it re-initialises lazily afterwards."""
     rc = lib.anemoi_release(device)
@@ -145,10 +165,17 @@ def release(device=ALL_DEVICES):
         raise AnemoiError(rc, lib.anemoi_last_error().decode())
 
 
-OPTIONS = ("coop_max", "coop2d_max", "coop4_max", "coop43_max", "coop2d43_max", "coop_sponge_max", "coop_climb_max",
+OPTIONS = ("coop2d_max", "coop4_max", "coop43_max", "coop2d43_max", "coop_sponge_max", "coop_climb_max",
            "virtual_devices", "host_staging", "chunk_target_bytes", "test_quantum",
            "sponge_segment_bytes")
 AUTO = -1
+
+
+def is_ab_build():
+    """True when the loaded library is a laboratory build (`make AB=1`): it knows the option `coop_max`, which routes to the
+    one-item-per-wavefront kernels the product does not contain."""
+    v = ctypes.c_longlong(0)
+    return lib.anemoi_get_option(b"coop_max", ctypes.byref(v)) == 0
 
 
 def set_option(name, value):

@@ -21,7 +21,7 @@ namespace anemoi {
 // Lanes per item -> the cooperative arithmetic:
 //   16   the digit-serial scan of coop29.h, one item per DPP row (four per wavefront)
 //   32   the two-row fold product of coop2d.h (two items per wavefront)
-//   64   one item per wavefront (A/B and parity only): the FOUR-row fold product where it exists (11-limb fields), else
+//   64   one item per wavefront (`make AB=1` libraries only): the FOUR-row fold product where it exists (11-limb fields), else
 //        the one-element scan of coop29.h (rounds 1-2's kernel)
 #ifdef ANEMOI_BOUNDS_WALK   // host walk of the bounds (tests/cpp/bounds_walk): a recording arithmetic in place of both
 template <class F, int LPI>
@@ -33,8 +33,10 @@ template <class F, int LPI, bool FOUR_ROWS = (F::Fold::Q4 > 0)>
 struct CoopArith { using type = Coop29<F, LPI>; };
 template <class F, bool FR>
 struct CoopArith<F, 32, FR> { using type = Coop2d<F, 2>; };
+#if ANEMOI_AB_BUILD
 template <class F>
 struct CoopArith<F, 64, true> { using type = Coop2d<F, 4>; };
+#endif
 #endif
 
 // ---- wave-cooperative Jive 2-to-1 compression (coop29.h, coop2d.h) ------------------------------------
@@ -59,7 +61,9 @@ struct CoopArith<F, 64, true> { using type = Coop2d<F, 4>; };
 // profiles/r04/coop_kernel_sweep.txt): its two extra swap levels and three-row form builds leave 18 hazard slots per
 // product that nothing can fill (86 issue slots against 79), and a lone wavefront pays for every slot.  On the 15-limb
 // fields it is rounds 1-2's one-element scan kernel.
+#if ANEMOI_AB_BUILD
 inline size_t coop_max_items() { return size_t(opt::get_or(opt::kCoopMax, 0)); }
+#endif
 // Anemoi-2-1 batches up to this size take the two-row fold kernels (coop2d.h, two items per wavefront): one
 // wavefront per SIMD -- beyond that the second wavefront of a SIMD costs more than the scan kernel's extra instructions
 inline size_t coop2d_max_items(int simds) { return size_t(opt::get_or(opt::kCoop2dMax, 2ll * simds)); }

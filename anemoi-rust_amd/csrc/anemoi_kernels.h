@@ -44,29 +44,20 @@ constexpr int kBlock = 64;  // one wavefront per workgroup: the LDS window table
 // Register budget: ANEMOI_WAVES waves per SIMD (0 = let the compiler choose; the shipped setting).
 // Forcing 5-8 waves/SIMD was measured and is slower: the kernels are VALU-issue bound at 3 waves
 // (profiles/r01/ab_occupancy_variants.txt).
-#ifndef ANEMOI_WAVES
-#define ANEMOI_WAVES 0
-#endif
-#if ANEMOI_WAVES > 0
+#if ANEMOI_WAVES > 0   // (A/B builds only, build_config.h)
 #define ANEMOI_KERNEL __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ANEMOI_WAVES, 8)))
 #else
 #define ANEMOI_KERNEL __global__ __launch_bounds__(kBlock)
 #endif
 
-#ifndef ANEMOI_HOLD_INPUTS_MAX_NL
-#define ANEMOI_HOLD_INPUTS_MAX_NL 13  // k_jive 2-1 keeps the feed-forward sum in VGPRs up to this many limbs
-#endif
-#ifndef ANEMOI_WIN
-#define ANEMOI_WIN 3  // 3 LDS entries per lane -> 13 waves per CU; see DESIGN.md section 3.3
-#endif
+// build_config.h: ANEMOI_HOLD_INPUTS_MAX_NL = 13 (k_jive 2-1 keeps the feed-forward sum in VGPRs up to this many limbs),
+// ANEMOI_WIN = 3 (3 LDS entries per lane -> 13 waves per CU)
 template <int N>
 struct KernelCfg {
   static constexpr int WIN = ANEMOI_WIN;  // sliding-window bits -> 2^(WIN-1) odd powers per lane in LDS
 };
 
-#ifndef ANEMOI_LDS_ENTRIES_9
-#define ANEMOI_LDS_ENTRIES_9 0  // A/B knob: LDS table entries requested by the 9-limb fields (0 = what the window needs)
-#endif
+// (ANEMOI_LDS_ENTRIES_9, A/B builds: LDS table entries requested by the 9-limb fields; 0 = what the window needs)
 template <class A, int WIN>
 constexpr size_t lds_table_bytes() {
   // x^3, x^5, ..: x itself stays in VGPRs
@@ -679,6 +670,9 @@ struct FieldOps {
   // items one full wave of workgroups of a batch kernel processes on the current device (every CU at its
   // resident-workgroup limit, from the occupancy API): the chunk quantum of the host-pointer pipeline
   size_t (*wave_items)(int kind, int width, int num_cus);
+  // one small launch of every THROUGHPUT kernel of (field, width) -- Jive, permutation, sponge over bytes and over
+  // elements -- on n items of zeros (d_buf: n states, d_out: n states of room): anemoi_warmup
+  hipError_t (*warmup)(int width, void* d_buf, void* d_out, size_t n, PermConsts pc, hipStream_t s);
 };
 
 enum KernelKind { kKindPermutation = 0, kKindJive = 1, kKindSponge = 2, kKindConvert = 3, kKindExpAlpha = 4 };
@@ -780,11 +774,13 @@ struct Launch {
 
   static hipError_t jive(int width, int k, const void* in, void* out, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (width == 2 && n <= coop_max_items()) {  // A/B and parity only: one item per wavefront (four-row fold on 11 limbs, else the scan)
+#if ANEMOI_AB_BUILD   // the recorded negative: one item per wavefront (four-row fold on 11 limbs, else rounds 1-2's scan)
+    if (width == 2 && n <= coop_max_items()) {
       const unsigned g = n < 65536 ? unsigned(n) : 65536u;  // the kernel strides over items
       k_jive2_coop<FIELD, 64><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
+#endif
     if (width == 2 && pc.fold_c && n <= coop2d_max_items(pc.simds)) {  // two items per wavefront on row pairs: the lowest latency
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
@@ -939,6 +935,29 @@ struct Launch {
     return hipGetLastError();
   }
 
+  // The FIRST big dispatch of a process can spread its wavefronts unevenly over the SIMDs of a CU (3 on one, 1 on
+  // another where 2 + 2 fit: tools/ubench/first_launch_placement.hip, profiles/r05/ubench_first_launch_placement.txt); a
+  // kernel whose workgroups all start at once and run for the whole launch -- config 3: 2 048 wavefronts, 330 ms -- then
+  // takes x 1.5.  A launch of the same kernel that reaches every CU beforehand cures it (profiles/r04/
+  // first_launch_after_idle.txt: 4 096 messages do, 64 do not).  So: every lane-private kernel of the instance once, on
+  // n >= 16 x SIMDs items (>= 256 workgroups), one-element messages for the sponges.
+  static hipError_t warmup(int width, void* d_buf, void* d_out, size_t n, PermConsts pc, hipStream_t s) {
+    const SpongeSeg whole_b{nullptr, 0, size_t(F::kChunk), 1, 1}, whole_e{nullptr, 0, 1, 1, 1};
+    const size_t l1 = lds_bytes<A, WIN, 1>(), l2 = lds_bytes<A, WIN, 2>();
+    if (width == 2) {
+      k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, l2, s>>>((const uint4*)d_buf, (uint4*)d_out, n, pc);
+      k_permutation<FIELD, 2, false><<<grid_for(n), kBlock, l2, s>>>((uint4*)d_out, n, pc);
+      k_sponge<FIELD, 2, true><<<grid_for(n), kBlock, l1, s>>>(d_buf, size_t(F::kChunk), n, (uint4*)d_out, pc, whole_b);
+      k_sponge<FIELD, 2, false><<<grid_for(n), kBlock, l1, s>>>(d_buf, 1, n, (uint4*)d_out, pc, whole_e);
+    } else {
+      k_jive_pair<FIELD, 2><<<pair_grid(n), kBlock, l2, s>>>((const uint4*)d_buf, (uint4*)d_out, n, pc);
+      k_permutation_pair<FIELD, false><<<pair_grid(n), kBlock, l2, s>>>((uint4*)d_out, n, pc);
+      k_sponge_pair<FIELD, true><<<pair_grid(n), kBlock, l2, s>>>(d_buf, size_t(F::kChunk), n, (uint4*)d_out, pc, whole_b);
+      k_sponge_pair<FIELD, false><<<pair_grid(n), kBlock, l2, s>>>(d_buf, 1, n, (uint4*)d_out, pc, whole_e);
+    }
+    return hipGetLastError();
+  }
+
   template <class K>
   static size_t resident_items(K kernel, size_t lds, int items_per_wg, int num_cus) {
     int nb = 0;
@@ -969,7 +988,7 @@ struct Launch {
     static const FieldOps o{F::L64,       F::kChunk,    F::kRounds21,        F::kRounds43, F::kG, F::kAlpha, F::kName,
                             host_consts,  permutation,  jive,                sponge,       sponge_seg,   sponge_ragged, mont_convert,
                             merkle_climb, generic_permutation, generic_jive, generic_sponge, exp_alpha,
-                            generic_prepare, generic_stride<A>(), wave_items};
+                            generic_prepare, generic_stride<A>(), wave_items, warmup};
     return &o;
   }
 };

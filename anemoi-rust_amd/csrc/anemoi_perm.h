@@ -22,9 +22,7 @@
 #include "mont29.h"
 #include "mont32.h"
 
-#ifndef ANEMOI_XDIGITS_ON
-#define ANEMOI_XDIGITS_ON 1  // extra window digits in VGPRs (exp_inv_alpha); 0 = plain window (A/B)
-#endif
+// ANEMOI_XDIGITS_ON (build_config.h): extra window digits in VGPRs (exp_inv_alpha); 0 = plain window (A/B builds)
 
 namespace anemoi {
 
@@ -39,23 +37,23 @@ __device__ __forceinline__ void static_for(Fn&& fn) {
   }
 }
 
-// Every field runs on 29-bit unsaturated limbs (14 limbs for 381/377 bits, 9 for 253..255 bits).
-// ANEMOI_ARITH32_FIELDS (a bit mask of field ids) keeps selected fields on the 32-bit-limb path
-// for A/B runs.
-#ifndef ANEMOI_ARITH32_FIELDS
-#define ANEMOI_ARITH32_FIELDS 0
-#endif
-#ifdef ANEMOI_BOUNDS_WALK
-// tests/cpp/bounds_walk: the kernel bodies compiled for the HOST over an arithmetic that records every operation, so
-// that the lazy-reduction bounds are walked on the code the kernels are made of (tests/test_bounds_walk.py)
+// Every field runs on unsaturated limbs (mont29.h: 13 limbs of 30 bits for 381/377 bits, 9 of 29 for 253..255 bits).
+// A/B builds only: ANEMOI_ARITH32_FIELDS (a bit mask of field ids) puts selected fields on the saturated 32-bit-limb
+// arithmetic of round 1 (mont32.h; 4.3 M against 10.6 M BLS12-381 compressions/s).
+#if defined(ANEMOI_BOUNDS_WALK)
+// tests/cpp/bounds_walk: the kernel bodies compiled for the HOST over an arithmetic that carries a bound of every value,
+// so that the lazy-reduction bounds are walked on the code the kernels are made of (tests/test_bounds_walk.py)
 template <class F>
 struct BoundsWalkArith;
 template <int FIELD>
 using ArithFor = BoundsWalkArith<FieldC<FIELD>>;
-#else
+#elif ANEMOI_AB_BUILD
 template <int FIELD>
 using ArithFor = std::conditional_t<((ANEMOI_ARITH32_FIELDS >> FIELD) & 1) == 0, Arith29<FieldC<FIELD>>,
                                     Arith32<FieldC<FIELD>>>;
+#else
+template <int FIELD>
+using ArithFor = Arith29<FieldC<FIELD>>;
 #endif
 
 // Per-lane window table in LDS: entries 1.. = x^3, x^5, ...; entry e, slot q of this lane at
@@ -291,9 +289,6 @@ __device__ __forceinline__ void sbox_layer(typename A::Fe (&st)[W], const PermCo
 // residency of 0.79 and the launch is ~12 % slower than two fair halves would be (profiles/r03/pmc_configs.json).
 // Alternating the wave priority round by round, in opposite phase for even and odd wave slots of a SIMD, makes the
 // two take turns and finish together.  With 3-4 resident wavefronts (the full batches) it changes nothing.
-#ifndef ANEMOI_ALT_PRIO
-#define ANEMOI_ALT_PRIO 1
-#endif
 __device__ __forceinline__ uint32_t wave_slot() {
 #if ANEMOI_ALT_PRIO
   return __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u;   // HW_ID.wave_id[3:0]: the slot on its SIMD

@@ -459,6 +459,30 @@ __global__ void k_assemble4(const uint4* __restrict__ cur, const uint4* __restri
   states[t] = v;
 }
 
+// anemoi_probe_issue_rate: every lane runs ONE dependent chain of v_mad_u64_u32 -- the instruction that carries the
+// throughput kernels (75 % of their instructions) -- with the register footprint of those kernels (161 VGPRs claimed:
+// three wavefronts per SIMD, launched as exactly three per SIMD), and stamps the shader clock (s_memtime) and the
+// 100 MHz wall clock (s_memrealtime) around the loop.
+__global__ __launch_bounds__(64) void k_issue_probe(uint64_t* __restrict__ rec, int iters) {
+  asm volatile("v_mov_b32 v160, 0" ::: "v160");
+  uint64_t acc = threadIdx.x + 1;
+  const uint32_t a = 0x9e3779b9u ^ threadIdx.x, b = blockIdx.x | 1u;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+#pragma nounroll
+  for (int i = 0; i < iters; i++) {
+#define ANEMOI_PROBE_MAD4 "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+#define ANEMOI_PROBE_MAD16 ANEMOI_PROBE_MAD4 ANEMOI_PROBE_MAD4 ANEMOI_PROBE_MAD4 ANEMOI_PROBE_MAD4
+    asm volatile(ANEMOI_PROBE_MAD16 ANEMOI_PROBE_MAD16 ANEMOI_PROBE_MAD16 ANEMOI_PROBE_MAD16 : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+  }
+  const uint64_t c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    rec[3 * blockIdx.x] = t1 - t0;
+    rec[3 * blockIdx.x + 1] = c1 - c0;
+  }
+  if (acc == 0x5a5a5a5a5a5a5a5aull) rec[3 * blockIdx.x + 2] = acc;   // keeps the chain alive; never true in practice
+}
+constexpr int kProbeMadsPerIter = 64;
+
 // Root / retained tree over arity^depth host leaves, on one device or sharded into subtrees over all
 // devices (the only cross-GPU data: one subtree root per part, finished on the first device).
 int merkle_host(TreeShape ts, const uint64_t* leaves, unsigned depth, uint64_t* root, uint64_t* tree, int device) {
@@ -508,7 +532,7 @@ int merkle_host(TreeShape ts, const uint64_t* leaves, unsigned depth, uint64_t* 
 
 extern "C" {
 
-int anemoi_abi_version(void) { return 3; }
+int anemoi_abi_version(void) { return 4; }
 
 int anemoi_device_count(void) {
   int n = 0;
@@ -581,6 +605,68 @@ int anemoi_init(int device, int field, int width) {
     rt::release_lane(ln);
   }
   return ANEMOI_OK;
+}
+
+int anemoi_warmup(int device, int field, int width) {
+  int rc = anemoi_init(device, field, width);
+  if (rc) return rc;
+  int ndev = 0;
+  if ((rc = rt::physical_devices(&ndev))) return rc;
+  const int lo = device == ANEMOI_ALL_DEVICES ? 0 : device, hi = device == ANEMOI_ALL_DEVICES ? ndev : device + 1;
+  const anemoi::FieldOps* ops = anemoi::field_ops(field);
+  for (int d = lo; d < hi; d++) {
+    rc = with_lane(d, [&](Lane& ln) -> int {
+      PermConsts pc;
+      int r = get_consts(field, width, &pc);
+      if (r) return r;
+      const size_t n = size_t(16) * size_t(pc.simds), bytes = n * size_t(width) * elem_bytes(field);
+      if ((r = ln.slot[0].d_in.reserve(bytes)) || (r = ln.slot[0].d_out.reserve(bytes))) return r;
+      HIP_TRY(hipMemsetAsync(ln.slot[0].d_in.p, 0, bytes, ln.s_k));   // zeros are canonical elements and valid messages
+      HIP_TRY(ops->warmup(width, ln.slot[0].d_in.p, ln.slot[0].d_out.p, n, pc, ln.s_k));
+      HIP_TRY(hipStreamSynchronize(ln.s_k));
+      return ANEMOI_OK;
+    });
+    if (rc) return rc;
+  }
+  return ANEMOI_OK;
+}
+
+int anemoi_probe_issue_rate(int device, double* lane_mad_per_s, double* shader_clock_ghz) {
+  if (!lane_mad_per_s || !shader_clock_ghz) return ANEMOI_ERR_ARG;
+  int ndev = 0, rc = rt::physical_devices(&ndev);
+  if (rc) return rc;
+  if (device < 0 || device >= ndev) {
+    g_last_error = "device ordinal out of range";
+    return ANEMOI_ERR_DEVICE;
+  }
+  return with_lane(device, [&](Lane& ln) -> int {
+    const int simds = 4 * rt::device_cus(device), grid = 3 * simds, iters = 60000;   // ~20 ms
+    int r = ln.slot[0].d_out.reserve(size_t(grid) * 3 * sizeof(uint64_t));
+    if (r) return r;
+    uint64_t* rec = (uint64_t*)ln.slot[0].d_out.p;
+    hipEvent_t a = nullptr, b = nullptr;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    k_issue_probe<<<grid, 64, 0, ln.s_k>>>(rec, iters / 8);   // untimed: the clock the timed launch sees is a loaded one
+    (void)hipEventRecord(a, ln.s_k);
+    k_issue_probe<<<grid, 64, 0, ln.s_k>>>(rec, iters);
+    (void)hipEventRecord(b, ln.s_k);
+    hipError_t e = hipEventSynchronize(b);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    std::vector<uint64_t> h(size_t(grid) * 3);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), rec, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIP_TRY(e);
+    std::vector<double> ghz;
+    for (int i = 0; i < grid; i++)
+      if (h[3 * i]) ghz.push_back(double(h[3 * i + 1]) / double(h[3 * i]) * 0.1);   // cycles per 10 ns tick
+    std::sort(ghz.begin(), ghz.end());
+    *shader_clock_ghz = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
+    *lane_mad_per_s = double(grid) * 64.0 * double(iters) * kProbeMadsPerIter / (double(ms) * 1e-3);
+    return ANEMOI_OK;
+  });
 }
 
 int anemoi_release(int device) {

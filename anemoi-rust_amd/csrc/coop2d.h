@@ -33,17 +33,13 @@
 #include <type_traits>
 
 #include "field_consts_gen.h"
-#if defined(ANEMOI_COOP2D_NOVDST) && ANEMOI_COOP2D_NOVDST
-#include "coop2d_asm_gen_novdst.h"   // A/B: the same statements without hazard padding of DPP destinations (not shipped)
+#include "build_config.h"
+#if ANEMOI_COOP2D_NOVDST   // A/B builds: the same statements without hazard padding of DPP destinations (generate the header
+#include "coop2d_asm_gen_novdst.h"   // with ANEMOI_COOP2D_GEN_NOVDST=1 python tools/gen_coop2d_asm.py; it is not part of the tree)
 #else
 #include "coop2d_asm_gen.h"   // tools/gen_coop2d_asm.py: the product below, hand-scheduled
 #endif
-#ifndef ANEMOI_COOP2D_FUSE
-#define ANEMOI_COOP2D_FUSE 1     // 0: an exponentiation step = a squaring-run statement + a multiplication statement (A/B)
-#endif
-#ifndef ANEMOI_ASM_MUL
-#define ANEMOI_ASM_MUL 1
-#endif
+// ANEMOI_COOP2D_FUSE (build_config.h; 0 in A/B builds: an exponentiation step = a squaring-run statement + a multiplication statement)
 
 namespace anemoi {
 
@@ -51,11 +47,12 @@ namespace anemoi {
 // per wavefront -- row r multiplies by the limbs a_i, i = r (mod 4), so a phase takes ceil(NL / 4) steps: half the
 // multiply-adds, broadcasts and shifts per wavefront for a second swap level (v_permlane32_swap) in the sums over the
 // rows.  Built, bit-exact, and MEASURED SLOWER than two rows (18 unfillable hazard slots per product against 6: 86 issue
-// slots against 79; Jubjub 1.073 vs 0.960 ms): kept selectable (option coop_max) as the recorded negative, not routed to.
+// slots against 79; Jubjub 1.073 vs 0.960 ms): the recorded negative, compiled into `make AB=1` libraries only (option coop_max).
 template <class F, int ROWS = 2>
 struct Coop2d {
   using L = typename F::Fold;
   static_assert(ROWS == 2 || (ROWS == 4 && L::Q4 > 0), "four rows: 11-limb fields only (the S form shifts b up by three lanes)");
+  static_assert(ROWS == 2 || ANEMOI_AB_BUILD, "the four-row form is a recorded negative: make AB=1");
   static constexpr int W = L::W, NL = L::NL, Q = ROWS == 2 ? L::Q : L::Q4, OFF = L::OFF;
   static constexpr int NABI = F::N;
   static constexpr int kLanesPerItem = 16 * ROWS;
@@ -198,7 +195,9 @@ struct Coop2d {
   }
   // the readable form of the same product (ANEMOI_ASM_MUL=0 builds run it)
   __device__ static __forceinline__ uint32_t mul_cxx(uint32_t a, uint32_t b, const K& k) {
+#if ANEMOI_AB_BUILD
     if constexpr (ROWS == 4) return mul_cxx4(a, b, k);
+#endif
     const uint32_t aD = odd_rows_from_next(a), bS = odd_rows_from_prev(b);
     uint64_t LO = 0, HI = 0;
     static_for<0>([&](auto I) {   // P1
@@ -252,7 +251,8 @@ struct Coop2d {
     }
   }
 
-  // ---- four rows per element (tools/coop2d_model.py::mul4) -------------------------------------------------------------
+#if ANEMOI_AB_BUILD
+  // ---- four rows per element (tools/coop2d_model.py::mul4): `make AB=1` libraries only ---------------------------------------
   __device__ static __forceinline__ void swap32(uint32_t& a, uint32_t& b) {   // rows 2, 3 of a <-> rows 0, 1 of b
     auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     a = r[0];
@@ -307,6 +307,7 @@ struct Coop2d {
     const uint32_t w = ((uint32_t)tot & MASK) + from_prev((uint32_t)(tot >> W));
     return (w & MASK) + from_prev(w >> W);
   }
+#endif  // ANEMOI_AB_BUILD
 
   // Digit-serial Montgomery product (the scan of coop29.h on this layout, both rows doing the same work): result
   // < (A B / H + 1) p.  Only where a result has to be < 2p: the conversion to the ABI form.

@@ -21,11 +21,10 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
-// ANEMOI_ASM_MUL = 1: squaring / multiplication come from the generated hand-scheduled assembly
-// (mont29_asm_gen.h, tools/gen_asm_mul.py) instead of the C++ below.
-#ifndef ANEMOI_ASM_MUL
-#define ANEMOI_ASM_MUL 1
-#endif
+#include "build_config.h"
+// ANEMOI_ASM_MUL = 1 (the product): squaring / multiplication come from the generated hand-scheduled assembly
+// (mont29_asm_gen.h, tools/gen_asm_mul.py); 0 (A/B builds, the host walk of the bounds): the C++ below, which is the
+// readable specification of the same arithmetic.
 #if ANEMOI_ASM_MUL
 #include "mont29_asm_gen.h"
 #endif

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "build_config.h"
+
 namespace anemoi {
 
 template <int N>
@@ -23,9 +25,8 @@ struct Fe {
   uint32_t l[N];
 };
 
-#ifndef ANEMOI_MAC_MODE
-#define ANEMOI_MAC_MODE 0
-#endif
+// ANEMOI_MAC_MODE (build_config.h): 1 = the shipped multiply-accumulate (asm v_mad_u64_u32 carry-out + deferred v_addc),
+// 0 = plain C++ (A/B builds, and the host compile of the bounds walk)
 
 #if ANEMOI_MAC_MODE == 0
 // ---- mode 0: plain C++ ------------------------------------------------------------------------

@@ -14,13 +14,15 @@
 #include <mutex>
 #include <string>
 
+#include "build_config.h"
+
 namespace anemoi {
 namespace opt {
 
 constexpr long long kAuto = -1;
 
 enum Id {
-  kCoopMax = 0,         // largest Jive 2-1 batch on the one-item-per-wavefront scan kernel (A/B only; auto = 0 = never)
+  kCoopMax = 0,         // A/B BUILDS ONLY (the product does not know the name): largest Jive 2-1 batch on the one-item-per-wavefront kernel
   kCoop2dMax,           // largest batch (Jive 2-1, permutation 2-1, sponge 2-1, path climb) on the two-row 2-D kernels
   kCoop4Max,            // largest Jive 2-1 / permutation batch on the row-cooperative kernel (four items per wavefront)
   kCoop43Max,           // largest Jive 4-3 / permutation batch on the row-cooperative 4-3 kernel (two states per wavefront)
@@ -39,11 +41,13 @@ struct Spec {
   const char* name;
   const char* env;
   long long lo, hi;  // accepted range (kAuto is always accepted)
+  bool ab_only = false;  // exists in `make AB=1` libraries only (routes to a kernel the product does not contain)
 };
+inline bool known(const Spec& s) { return ANEMOI_AB_BUILD || !s.ab_only; }
 
 inline const Spec& spec(int id) {
   static const Spec table[kCount] = {
-      {"coop_max", "ANEMOI_COOP_MAX", 0, 1ll << 62},
+      {"coop_max", "ANEMOI_COOP_MAX", 0, 1ll << 62, true},
       {"coop2d_max", "ANEMOI_COOP2D_MAX", 0, 1ll << 62},
       {"coop4_max", "ANEMOI_COOP4_MAX", 0, 1ll << 62},
       {"coop43_max", "ANEMOI_COOP43_MAX", 0, 1ll << 62},
@@ -89,7 +93,8 @@ inline void init_once() {
   std::call_once(s.once, [&] {
     for (int i = 0; i < kCount; i++) {
       long long v = kAuto;
-      if (const char* e = getenv(spec(i).env)) {
+      const char* e = known(spec(i)) ? getenv(spec(i).env) : nullptr;
+      if (e) {
         if (!parse(i, e, &v)) {
           v = kAuto;
           s.env_error += std::string(s.env_error.empty() ? "" : "; ") + spec(i).env + "=\"" + e + "\" ignored (not a value in range)";
@@ -111,7 +116,7 @@ inline long long get_or(Id id, long long automatic) {
 inline int find(const char* name) {
   if (!name) return -1;
   for (int i = 0; i < kCount; i++)
-    if (!strcmp(name, spec(i).name) || !strcmp(name, spec(i).env)) return i;
+    if (known(spec(i)) && (!strcmp(name, spec(i).name) || !strcmp(name, spec(i).env))) return i;
   return -1;
 }
 inline bool set(int id, long long value) {

@@ -94,6 +94,21 @@ int anemoi_num_rounds(int field, int width); /* NUM_HASH_ROUNDS, src/<f>/anemoi_
  * kernels read the constant tables.  The library can be used again afterwards (it re-initialises lazily). */
 int anemoi_init(int device, int field, int width);
 int anemoi_release(int device);
+/* anemoi_init, then ONE small launch (16 x SIMDs items of zeros, a few ms) of every throughput kernel of (field, width):
+ * Jive, permutation, sponge over bytes and over elements.  Why: the first big dispatch of a process can place its
+ * wavefronts unevenly over the SIMDs of a CU (three on one, one on another); a launch whose workgroups all start at
+ * once and stay for its whole duration -- 2^16 long messages: 2 048 wavefronts for a third of a second -- then takes
+ * x 1.5 (profiles/r05/).  A service that cares about its FIRST large call calls this at start-up;
+ * it waits for its launches, so it is not for capture either. */
+int anemoi_warmup(int device, int field, int width);
+
+/* ---- diagnostics ----------------------------------------------------------------------------
+ * What this GPU delivers right now of the one instruction that carries the throughput kernels: a full grid (three
+ * wavefronts per SIMD) of dependent v_mad_u64_u32 chains for ~20 ms on `device`.  *lane_mad_per_s = lane multiply-adds
+ * per second (the 16-lanes-per-clock ceiling is SIMDs x 16 x clock); *shader_clock_ghz = the clock the chip held while
+ * it ran (s_memtime / s_memrealtime, median over the workgroups).  bench.py reports both beside its line, so that a
+ * slow box and a slow build can be told apart (boxes of one pool differ by several per cent under this load). */
+int anemoi_probe_issue_rate(int device, double *lane_mad_per_s, double *shader_clock_ghz);
 
 /* ---- options --------------------------------------------------------------------------------
  * anemoi_set_option(name, value): value -1 = automatic (the default).  `name` is the option name or its environment
@@ -113,7 +128,8 @@ int anemoi_release(int device);
  *                                                                                      row pair: lowest latency); above: coop43_max's kernel
  *   coop_sponge_max        ANEMOI_COOP_SPONGE_MAX       4 x SIMDs                      largest equal-length sponge batch on the cooperative kernel
  *   coop_climb_max         ANEMOI_COOP_CLIMB_MAX        4 x SIMDs                      largest batch of authentication paths on the cooperative kernel
- *   coop_max               ANEMOI_COOP_MAX              0                              one-item-per-wavefront scan kernel (A/B and parity only)
+ *   (Laboratory libraries built with `make AB=1` also know coop_max / ANEMOI_COOP_MAX: the one-item-per-wavefront kernels that
+ *   measured slower and are not compiled into the product.  The product answers ANEMOI_ERR_ARG for that name.)
  *   virtual_devices        ANEMOI_VIRTUAL_DEVICES       the GPU count                  ANEMOI_ALL_DEVICES shards into this many ranges / subtrees,
  *                                                                                      mapped round-robin onto the GPUs (multi-GPU code on one GPU)
  *   host_staging           ANEMOI_HOST_STAGING          1 ("pinned")                   1: host buffers go through the lane's pinned staging;

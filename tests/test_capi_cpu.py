@@ -35,7 +35,7 @@ def test_binding_covers_every_declared_symbol(A):
 
 
 def test_introspection(A, params):
-    assert A.lib.anemoi_abi_version() == 3
+    assert A.lib.anemoi_abi_version() == 4
     for fid, name in enumerate(FIELD_IDS):
         assert A.lib.anemoi_field_name(fid).decode() == name
         assert A.field_id(name) == fid

@@ -34,9 +34,10 @@ def rand_elems(oracle, fid, modulus, count, seed):
 # small batches take the cooperative latency kernels by default -- the two-row fold kernels (coop2d.h: two 2-1 items or
 # one 4-3 state per wavefront); "row" switches the fold kernels off (everything on the row-cooperative scan
 # kernels), "lane" forces the lane-private throughput kernels.  (The one-item-per-wavefront kernels -- four-row fold /
-# scan -- are forced in test_cooperative_and_lane_private_paths_agree and in the fuzz.)
-LATENCY_KERNELS = {"default": {}, "row": {"coop_max": 0, "coop2d_max": 0, "coop2d43_max": 0},
-                   "lane": {"coop_max": 0, "coop2d_max": 0, "coop4_max": 0, "coop43_max": 0, "coop2d43_max": 0,
+# scan, the recorded negatives -- exist in `make AB=1` libraries only; test_cooperative_and_lane_private_paths_agree and
+# the fuzz force them when ANEMOI_MI355X_LIB points at one: the product ignores ANEMOI_COOP_MAX.)
+LATENCY_KERNELS = {"default": {}, "row": {"coop2d_max": 0, "coop2d43_max": 0},
+                   "lane": {"coop2d_max": 0, "coop4_max": 0, "coop43_max": 0, "coop2d43_max": 0,
                             "coop_sponge_max": 0, "coop_climb_max": 0}}
 
 
@@ -468,8 +469,8 @@ for fid, field in enumerate(A.FIELD_IDS):
         assert (inst4.hash_field_batch(el) == oracle.hash_field_batch(fid, 4, el, threads=1)).all(), (field, ne)
 print("ok")
 '''.replace("ROOT", repr(ROOT))
-    # (lane-private; one-per-wavefront + row-cooperative 4-3; row-cooperative scan 2-1; two-row fold 2-1 AND 4-3): each
-    # forced for every size
+    # (lane-private; [laboratory build: one-per-wavefront 2-1 +] row-cooperative 4-3; row-cooperative scan 2-1; two-row fold
+    # 2-1 AND 4-3): each forced for every size
     for coop_max, coop2d_max, coop4_max, coop43_max, coop2d43_max in (
             ("0", "0", "0", "0", "0"), ("1000000000", "0", "0", "1000000000", "0"), ("0", "0", "1000000000", "1", "0"),
             ("0", "1000000000", "0", "0", "1000000000")):

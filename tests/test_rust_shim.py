@@ -58,6 +58,7 @@ def type_table():
         "size_t": (C.c_size_t, "usize"),
         "long long": (C.c_longlong, "c_longlong"),
         "long long *": (P(C.c_longlong), "*mut c_longlong"),
+        "double *": (P(C.c_double), "*mut c_double"),
         "uint64_t *": (P(C.c_uint64), "*mut u64"),
         "const uint64_t *": (P(C.c_uint64), "*const u64"),
         "uint8_t *": (P(C.c_uint8), "*mut u8"),

@@ -35,7 +35,7 @@ for _ in range(3):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(s); run_dev(); b.record(s); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
 root_dev = d_root.cpu().numpy().view(np.uint64)
-print("%s depth %d, device-resident, one stream (COOP_MAX=%s): %.2f ms" % (field, depth, A.get_option("coop_max"), sorted(ts)[1]))
+print("%s depth %d, device-resident, one stream (coop2d_max=%s): %.2f ms" % (field, depth, A.get_option("coop2d_max"), sorted(ts)[1]))
 
 if len(sys.argv) > 3:  # per-level times: one launch per level, events around each
     pc = []

@@ -521,13 +521,18 @@ def main():
          "// is its specification) as hand-scheduled gfx950 assembly: a multiplication, a run of squarings, and a run of",
          "// squarings followed by a multiplication (one exponentiation step), the loops inside the statements.",
          "// Layout-driven (limbs, limb bits): the fold table arrives as operands.",
-         "#pragma once", "#include <hip/hip_runtime.h>", "#include <cstdint>", "namespace anemoi {",
+         "// The four-row statements (ROWS = 4, the recorded negative) are compiled into `make AB=1` libraries only.",
+         "#pragma once", "#include <hip/hip_runtime.h>", "#include <cstdint>", '#include "build_config.h"', "namespace anemoi {",
          "template <int NL, int W, int ROWS = 2> struct AsmCoop2d;   // ROWS 16-lane rows per element"]
     for nl, W in LAYOUTS:
         for rows in ((2, 4) if nl <= 13 else (2,)):
+            if rows == 4:
+                h.append("#if ANEMOI_AB_BUILD")
             h.append("template <> struct AsmCoop2d<%d, %d, %d> {" % (nl, W, rows))
             h += render(nl, W, rows)
             h.append("};")
+            if rows == 4:
+                h.append("#endif  // ANEMOI_AB_BUILD")
     h.append("}  // namespace anemoi")
     dst = os.path.join(ROOT, "anemoi-rust_amd", "csrc", os.environ.get("ANEMOI_COOP2D_GEN_OUT") or
                        ("coop2d_asm_gen.h" if PAD_DPP_DST else "coop2d_asm_gen_novdst.h"))

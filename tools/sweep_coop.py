@@ -23,6 +23,7 @@ s = torch.cuda.current_stream()
 BIG = 1000000000
 # mode -> (coop_max, coop2d_max, coop4_max)
 MODES = {"coop2d": (0, BIG, 0), "coop4": (0, 0, BIG), "coop1": (BIG, 0, 0), "lane": (0, 0, 0)}
+AB = A.is_ab_build()   # "coop1" (one item per wavefront) exists in `make AB=1` libraries only: ANEMOI_MI355X_LIB=.../libanemoi_ab.so
 
 
 def timed(fid, d_in, d_out, n, reps=5):
@@ -48,9 +49,11 @@ for field in fields:
     for n in sizes:
         row, ref = {}, None
         for mode, (c1, c2, c4) in MODES.items():
-            if (mode == "coop1" and n > 4096) or (mode == "coop2d" and n > 16384):
+            if (mode == "coop1" and (n > 4096 or not AB)) or (mode == "coop2d" and n > 16384):
                 continue     # tens of thousands of wavefronts of a latency kernel are pointless
-            A.set_option("coop_max", c1); A.set_option("coop2d_max", c2); A.set_option("coop4_max", c4)
+            if AB:
+                A.set_option("coop_max", c1)
+            A.set_option("coop2d_max", c2); A.set_option("coop4_max", c4)
             d_out = torch.zeros(n * L, dtype=torch.int64, device=dev)
             row[mode] = timed(fid, d_in, d_out, n)
             got = d_out.cpu()
@@ -61,7 +64,7 @@ for field in fields:
         best = min(row, key=row.get)
         print("%8d %9s %9.3f %9s %9.3f   %s" % (n, "%9.3f" % row["coop2d"] if "coop2d" in row else "-", row["coop4"],
                                                "%9.3f" % row["coop1"] if "coop1" in row else "-", row["lane"], best))
-    for o in ("coop_max", "coop2d_max", "coop4_max"):
+    for o in (("coop_max",) if AB else ()) + ("coop2d_max", "coop4_max"):
         A.set_option(o, None)
 
     def tree_ms(depth, c2max, c4max):
