@@ -1,7 +1,8 @@
-"""bench.py's N > 1 host logic on CPU, two processes over gloo: rank -> shard of config 4, the seeded
-generator producing a rank's slice on its own, the comparison of a rank's outputs with the committed
-oracle goldens (here the oracle stands in for the kernel on the sampled items only -- 2^21 compressions
-per rank are a GPU-sized job), and the all-ranks failure flag that makes every rank exit when one rank's
+"""bench.py's N > 1 host logic on CPU, 2 / 4 / 8 processes over gloo -- 8 is the driver's first multi-GPU launch, which no
+box available to the builder can run: rank -> shard of config 4, the seeded generator producing a rank's slice on its
+own, the comparison of a rank's outputs with the committed oracle goldens (here the oracle stands in for the kernel on
+the sampled items only -- 2^21 compressions per rank are a GPU-sized job), the per-shard SHA-256 selection, the
+out-of-range guard, and the all-ranks failure flag that makes every rank exit when one rank's -- the LAST rank's --
 output is wrong."""
 import json
 import os
@@ -9,6 +10,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -54,23 +56,56 @@ def worker(rank, world, port, corrupt_rank, out_path):
     dist.destroy_process_group()
 
 
-def run(tmp_path, corrupt_rank):
-    out = str(tmp_path / ("res_%d.json" % corrupt_rank))
-    mp.spawn(worker, args=(2, free_port(), corrupt_rank, out), nprocs=2, join=True)
+def run(tmp_path, world, corrupt_rank):
+    out = str(tmp_path / ("res_%d_%d.json" % (world, corrupt_rank)))
+    mp.spawn(worker, args=(world, free_port(), corrupt_rank, out), nprocs=world, join=True)
     return json.load(open(out))
 
 
-def test_two_ranks_verify_their_config4_shards(tmp_path):
-    res = run(tmp_path, -1)
-    assert [(r[0], r[1], r[2]) for r in res] == [["cfg4", 0, 1 << 21], ["cfg4", 1 << 21, 1 << 21]] or \
-        [tuple(r[:3]) for r in res] == [("cfg4", 0, 1 << 21), ("cfg4", 1 << 21, 1 << 21)]
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_every_rank_verifies_its_config4_shard(tmp_path, world):
+    res = run(tmp_path, world, -1)
+    assert [tuple(r[:3]) for r in res] == [("cfg4", r << 21, 1 << 21) for r in range(world)]
     assert all(r[3] == 512 and r[4] is None and r[5] is False for r in res)
 
 
-def test_one_wrong_rank_fails_every_rank(tmp_path):
-    res = run(tmp_path, 1)
-    assert res[0][4] is None and res[1][4] and "item" in res[1][4]
-    assert all(r[5] is True for r in res)      # both ranks know, both would exit non-zero
+@pytest.mark.parametrize("world", [2, 8])
+def test_a_wrong_last_rank_fails_every_rank(tmp_path, world):
+    res = run(tmp_path, world, world - 1)
+    assert all(r[4] is None for r in res[:-1]) and res[-1][4] and "item" in res[-1][4]
+    assert all(r[5] is True for r in res)      # every rank knows, every rank would exit non-zero
+
+
+def test_shard_digest_selection_and_the_out_of_range_guard():
+    """verify_against_golden picks shard_sha256[first // n]: every one of 8 ranks must find ITS digest (a fake golden of
+    the real one's shape: 8 shards, a strided sample), a rank given another rank's outputs must not; rank_shard refuses
+    a rank whose shard would reach beyond the config's batch (9 ranks of 2^21, or 8 ranks of 2^22)."""
+    import hashlib
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "anemoi-rust_amd"))
+    os.environ["ANEMOI_NO_TORCH_PRELOAD"] = "1"
+    import bench
+    per, shards, stride = 64, 8, 16
+    rng = np.random.default_rng(9)
+    outs = rng.integers(0, 1 << 63, size=(per * shards, 6), dtype=np.uint64)
+    golden = {"n": per * shards, "shards": shards, "sample_stride": stride,
+              "sample": [outs[i].tobytes().hex() for i in range(0, per * shards, stride)],
+              "sha256": hashlib.sha256(outs.tobytes()).hexdigest(),
+              "shard_sha256": [hashlib.sha256(outs[r * per:(r + 1) * per].tobytes()).hexdigest() for r in range(shards)]}
+    for r in range(shards):
+        checked, sha_ok, err = bench.verify_against_golden(outs[r * per:(r + 1) * per], golden, r * per, per)
+        assert (checked, sha_ok, err) == (per // stride, True, None), r
+        other = outs[((r + 1) % shards) * per:((r + 1) % shards + 1) * per]
+        assert bench.verify_against_golden(other, golden, r * per, per)[2] is not None, r
+        bent = outs[r * per:(r + 1) * per].copy()
+        bent[stride + 1, 0] ^= np.uint64(1)                   # not a sampled item: only the shard's SHA-256 sees it
+        assert "SHA-256" in bench.verify_against_golden(bent, golden, r * per, per)[2], r
+    assert bench.verify_against_golden(outs, golden, 0, per * shards)[:2] == (per * shards // stride, True)
+    with pytest.raises(SystemExit):
+        bench.rank_shard(8, 9)
+    with pytest.raises(SystemExit):
+        bench.rank_shard(4, 8, batch_log2=22)
+    assert bench.rank_shard(7, 8)[2:] == (7 << 21, 1 << 21)
 
 
 def test_single_gpu_shard_is_config2():

@@ -398,7 +398,7 @@ def test_concurrent_callers_overlap_on_the_gpu(A, oracle):
 
 # ---------------------------------------------------------------- bench.py --gpus 2: the driver's N > 1 launch line
 
-def _bench_two_ranks(extra_env):
+def _bench_two_ranks(extra_env, ranks=2):
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as a CHILD process (started before this
     process's GPU state matters to it; nothing is exec'ed over a GPU-initialised process)."""
     import socket
@@ -412,8 +412,8 @@ def _bench_two_ranks(extra_env):
     env.pop("ANEMOI_BENCH_BACKEND", None)
     env.pop("ANEMOI_BENCH_TEST_CORRUPT_RANK", None)
     env.update(extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1"]
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
 
 
@@ -433,6 +433,20 @@ def test_bench_two_ranks_share_one_gpu_over_gloo(A):
     assert bad.returncode != 0, "a wrong shard on rank 1 must fail the whole run"
     assert not [l for l in bad.stdout.splitlines() if l.startswith("{")], "no result line when a rank's output is wrong"
     assert "rank 1" in bad.stderr
+
+
+def test_bench_four_ranks_share_one_gpu_over_gloo(A):
+    """Four ranks (shards 0 .. 3 of config 4) on the one GPU: offsets beyond the second shard, four per-shard digests, the
+    probe's min over ranks; then the LAST rank corrupted.  (Five processes on the card with this one: inside the limit.)"""
+    p = _bench_two_ranks({"ANEMOI_BENCH_BACKEND": "gloo"}, ranks=4)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 4 and line["verified"]["ranks"] == 4 and line["verified"]["sha256_of_all_outputs"] is True
+    assert line["config"]["parallelism"] == "shard4" and line["config"]["batch_per_gpu"] == 1 << 21
+    assert 0 < line["alu"]["probe_lane_mad_per_s_min_over_ranks"] <= line["alu"]["probe_lane_mad_per_s"] * 1.5
+    bad = _bench_two_ranks({"ANEMOI_BENCH_BACKEND": "gloo", "ANEMOI_BENCH_TEST_CORRUPT_RANK": "3"}, ranks=4)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+    assert "rank 3" in bad.stderr
 
 
 # ---------------------------------------------------------------- bench.py --gpus 2 over RCCL (needs >= 2 GPUs)
