@@ -82,6 +82,12 @@ inline size_t coop2d43_max_items(int simds) { return size_t(opt::get_or(opt::kCo
 // (1 KB messages: Jubjub 2-1 49.1 vs 86.5 ms up to 1 024 messages, 51.6 vs 86.7 at 4 096, 134.6 vs 86.8 at 16 384;
 // BN-254 4-3 12.0 vs 22.4 ms, 18.3 vs 22.4 at 4 096, 61.8 vs 22.9 at 16 384)
 inline size_t coop_sponge_max_items(int simds) { return size_t(opt::get_or(opt::kCoopSpongeMax, 4ll * simds)); }
+// the largest equal-length sponge batch ANY cooperative kernel takes (Launch::sponge_seg routes on these three): what
+// the host path means by "a latency batch"
+inline size_t sponge_latency_max_items(int width, int simds) {
+  const size_t fold = width == 2 ? coop2d_max_items(simds) : coop2d43_max_items(simds), scan = coop_sponge_max_items(simds);
+  return fold > scan ? fold : scan;
+}
 // Batches of authentication paths up to this size climb on k_merkle_climb_coop (four paths per wavefront); its own
 // knob (round 3 borrowed the sponge's, so that one switched two kernels)
 inline size_t coop_climb_max_items(int simds) { return size_t(opt::get_or(opt::kCoopClimbMax, 4ll * simds)); }
@@ -369,9 +375,14 @@ __global__ __launch_bounds__(kBlock) void k_merkle_climb_coop(const uint32_t* __
 // row, state[2] = y of the even row; both rows of a pair decode the same element and the row that owns state[pos]
 // keeps the sum.  A byte message's element e is its chunk e (F::kChunk bytes, little-endian, a 0x01 byte appended to
 // a short last chunk, hasher.rs:36-57): lane j cuts its 29-bit limb out of the five bytes that hold it.
+// One launch absorbs one SEGMENT of every message (SpongeSeg, anemoi_kernels.h; the whole message when first = last = 1):
+// a small batch of LONG messages from host memory is fed segment by segment (capi.hip sponge_segments) and keeps the
+// latency kernel -- round 4 sent every segmented batch to the lane-private kernels, which at a few thousand messages
+// run one wavefront per 16 SIMDs (12.0 against 22.4 ms per 1 KB at 1 024 messages).  The state travels between the
+// launches as canonical ABI elements, exactly as k_sponge's does.
 template <int FIELD, int W, bool BYTES, int LPR = 16>
 __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__ src, size_t per_msg, size_t n,
-                                                        uint32_t* __restrict__ out, PermConsts pc) {
+                                                        uint32_t* __restrict__ out, PermConsts pc, SpongeSeg seg) {
   using F = FieldC<FIELD>;
   using C = typename CoopArith<F, LPR>::type;
   static_assert(LPR <= 32 || W == 2, "the 4-3 form puts a state's two columns on two adjacent rows / row pairs");
@@ -381,23 +392,32 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
   const uint32_t lane = threadIdx.x, j = C::limb(), row = lane / LPR, col = W == 4 ? (row & 1) : 0;
   const bool odd = col != 0;
   const typename C::K k = C::load_consts();
-  const size_t num = BYTES ? (per_msg + F::kChunk - 1) / F::kChunk : per_msg;
+  // per_msg = this launch's bytes / elements per message (the stride of `src`); seg.total_len = the whole message
+  const size_t num = BYTES ? (seg.total_len + F::kChunk - 1) / F::kChunk : seg.total_len;
   const size_t total = num + (num % RATE == 0 ? 0 : 1);
+  const size_t e_end = seg.last ? total : seg.e0 + (BYTES ? per_msg / F::kChunk : per_msg);
   const size_t groups = (n + PER - 1) / PER;
   for (size_t g = blockIdx.x; g < groups; g += gridDim.x) {
     const size_t want = g * PER + (W == 2 ? row : row / 2);
     const bool live = want < n;
     const size_t item = live ? want : n - 1;
     const uint8_t* msg = (const uint8_t*)src + (BYTES ? item * per_msg : item * per_msg * NABI * 4);
+    // this column's part of the state: x = state[col], y = state[W/2 + col]
+    uint32_t* const sx_w = seg.state + (item * W + col) * NABI;
+    uint32_t* const sy_w = seg.state + (item * W + W / 2 + col) * NABI;
     uint32_t x = 0, y = 0;
+    if (!seg.first) {
+      x = C::from_abi(j < NABI ? sx_w[j] : 0u, k);
+      y = C::from_abi(j < NABI ? sy_w[j] : 0u, k);
+    }
     int pos = 0;
 #pragma nounroll
-    for (size_t e = 0; e < total; e++) {
+    for (size_t e = seg.e0; e < e_end; e++) {
       uint32_t el;
       if (e >= num) {
         el = k.one;
       } else if (BYTES) {
-        const size_t c0 = e * F::kChunk, left = per_msg - c0;
+        const size_t c0 = (e - seg.e0) * F::kChunk, left = seg.total_len - e * F::kChunk;
         const int clen = left < size_t(F::kChunk) ? int(left) : F::kChunk;
         const int bit = C::W * int(j), b0 = bit >> 3, sh = bit & 7;
         uint64_t v = 0;
@@ -414,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
         const uint32_t limb = j < NL ? uint32_t(v >> sh) & C::MASK : 0u;
         el = C::to_mont(limb, k);                 // plain integer < p -> Montgomery form
       } else {
-        const uint32_t w = j < NABI ? ((const uint32_t*)msg)[e * NABI + j] : 0u;
+        const uint32_t w = j < NABI ? ((const uint32_t*)msg)[(e - seg.e0) * NABI + j] : 0u;
         el = C::from_abi(w, k);
       }
       // pos is wave-uniform (every message has the same length)
@@ -430,6 +450,14 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
         coop_permutation<F, C, W>(x, y, k, tab, pc);
         pos = 0;
       }
+    }
+    if (!seg.last) {   // carry the state to the next segment's launch
+      const uint32_t ox = C::to_abi(x, k), oy = C::to_abi(y, k);
+      if (live && C::writer() && j < NABI) {
+        sx_w[j] = ox;
+        sy_w[j] = oy;
+      }
+      continue;
     }
     const uint32_t o = C::to_abi(x, k);   // digest = state[0]
     if (live && !odd && C::writer() && j < NABI) out[item * NABI + j] = o;

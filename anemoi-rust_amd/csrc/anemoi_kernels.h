@@ -468,16 +468,29 @@ __device__ __forceinline__ T wave_max(T v) {
   return v;
 }
 
+// digest -> out[message], straight from the lane (the bucketed order scatters its outputs)
+template <class A>
+__device__ __forceinline__ void store_digest(uint4* __restrict__ dst, const typename A::Fe& v) {
+  uint32_t w[A::NABI];
+  A::to_abi(w, v);
+#pragma unroll
+  for (int q = 0; q < A::NABI / 4; q++) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+
+// `order` (may be null): slot j of the launch works on message order[j] and its digest goes to out[order[j]] -- the
+// device-side bucketing of anemoi_hash_bytes_ragged_bucketed_dev (k_ragged_hist / _scan / _place below): messages by
+// descending block count, so that the lanes of a wavefront run out of blocks together.
 template <int FIELD>
 ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off, size_t n,
-                                   uint4* __restrict__ out, PermConsts pc) {
+                                   uint4* __restrict__ out, PermConsts pc, const uint32_t* __restrict__ order) {
   using F = FieldC<FIELD>;
   using A = ArithFor<FIELD>;
   constexpr int WIN = KernelCfg<F::N>::WIN;  // Anemoi-2-1: RATE = 1, a block is one element
   extern __shared__ uint4 lds[];
   const size_t blk0 = size_t(blockIdx.x) * kBlock;
   const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
-  const size_t item = blk0 + (threadIdx.x < cnt ? threadIdx.x : 0);  // idle lanes redo item blk0
+  const size_t slot = blk0 + (threadIdx.x < cnt ? threadIdx.x : 0);  // idle lanes redo item blk0
+  const size_t item = order ? size_t(order[slot]) : slot;
   const uint64_t o0 = off[item], len = off[item + 1] - o0;
   const uint8_t* msg = msgs + o0;
   const size_t num = (len + F::kChunk - 1) / F::kChunk;  // RATE = 1: no padding element ever
@@ -497,6 +510,10 @@ ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint6
     permutation<F, A, 2, WIN>(st, pc, tab);
     fe_select<A>(dig, b + 1 == blocks, st[0], dig);
   }
+  if (order) {
+    if (threadIdx.x < cnt) store_digest<A>(out + item * (A::NABI / 4), dig);
+    return;
+  }
   __syncthreads();
   lds_put<A>(lds, threadIdx.x, dig);
   block_store<A::NABI / 4>(lds, out, blk0, cnt);
@@ -504,7 +521,7 @@ ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint6
 
 template <int FIELD>
 ANEMOI_KERNEL void k_sponge_ragged_pair(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off, size_t n,
-                                        uint4* __restrict__ out, PermConsts pc) {
+                                        uint4* __restrict__ out, PermConsts pc, const uint32_t* __restrict__ order) {
   using F = FieldC<FIELD>;
   using A = ArithFor<FIELD>;
   constexpr int WIN = KernelCfg<F::N>::WIN, RATE = 3;
@@ -513,7 +530,8 @@ ANEMOI_KERNEL void k_sponge_ragged_pair(const uint8_t* __restrict__ msgs, const 
   const int cnt = n - st0 < size_t(kPairStates) ? int(n - st0) : kPairStates;
   const bool odd = threadIdx.x & 1;
   const int s = threadIdx.x >> 1;
-  const size_t item = st0 + (s < cnt ? s : 0);  // idle lane pairs redo item st0
+  const size_t slot = st0 + (s < cnt ? s : 0);  // idle lane pairs redo item st0
+  const size_t item = order ? size_t(order[slot]) : slot;
   const uint64_t o0 = off[item], len = off[item + 1] - o0;
   const uint8_t* msg = msgs + o0;
   const size_t num = (len + F::kChunk - 1) / F::kChunk;
@@ -543,6 +561,10 @@ ANEMOI_KERNEL void k_sponge_ragged_pair(const uint8_t* __restrict__ msgs, const 
     });
     permutation_pair<F, A, WIN>(x, y, odd, pc, tab);
     fe_select<A>(dig, b + 1 == blocks, x, dig);
+  }
+  if (order) {
+    if (!odd && s < cnt) store_digest<A>(out + item * (A::NABI / 4), dig);   // digest = state[0] = the even lane's x
+    return;
   }
   __syncthreads();
   lds_put<A>(lds, odd ? kPairStates + s : s, dig);  // digest = state[0] = the even lane's x
@@ -652,8 +674,9 @@ struct FieldOps {
   hipError_t (*sponge_seg)(int width, int bytes, const void* d_src, size_t per_msg, size_t n, void* d_out, PermConsts pc,
                            SpongeSeg seg, hipStream_t s);
   // messages of different lengths: message i = bytes [off[i], off[i+1]) of d_msgs
+  // d_order: null, or n 32-bit message indices (slot j works on message d_order[j] and writes out[d_order[j]])
   hipError_t (*sponge_ragged)(int width, const void* d_msgs, const void* d_off, size_t n, void* d_out, PermConsts pc,
-                              hipStream_t s);
+                              const void* d_order, hipStream_t s);
   hipError_t (*mont_convert)(int to, const void* d_in, void* d_out, size_t count, hipStream_t s);
   hipError_t (*merkle_climb)(const void* d_leaves, const void* d_index, const void* d_paths, unsigned depth, size_t n,
                              void* d_out, PermConsts pc, hipStream_t s);
@@ -745,12 +768,12 @@ struct Launch {
   static hipError_t permutation(int width, int sbox_only, void* d, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
     // latency path: the cut-offs of the Jive kernels (same permutation, same items per wavefront)
-    if (!sbox_only && width == 2 && pc.fold_c && n <= coop2d_max_items(pc.simds)) {
+    if (!sbox_only && width == 2 && n <= coop2d_max_items(pc.simds)) {
       const size_t groups = (n + 1) / 2;
       k_permutation_coop<FIELD, 2, 32><<<unsigned(groups < 65536 ? groups : 65536), kBlock, 0, s>>>((uint32_t*)d, n, pc);
       return hipGetLastError();
     }
-    if (!sbox_only && width == 4 && pc.fold_c && n <= coop2d43_max_items(pc.simds)) {   // one 4-3 state per wavefront, a column per row pair
+    if (!sbox_only && width == 4 && n <= coop2d43_max_items(pc.simds)) {   // one 4-3 state per wavefront, a column per row pair
       k_permutation_coop<FIELD, 4, 32><<<unsigned(n < 65536 ? n : 65536), kBlock, 0, s>>>((uint32_t*)d, n, pc);
       return hipGetLastError();
     }
@@ -781,7 +804,7 @@ struct Launch {
       return hipGetLastError();
     }
 #endif
-    if (width == 2 && pc.fold_c && n <= coop2d_max_items(pc.simds)) {  // two items per wavefront on row pairs: the lowest latency
+    if (width == 2 && n <= coop2d_max_items(pc.simds)) {  // two items per wavefront on row pairs: the lowest latency
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       k_jive2_coop<FIELD, 32><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
@@ -793,7 +816,7 @@ struct Launch {
       k_jive2_coop<FIELD, 16><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
-    if (width == 4 && pc.fold_c && n <= coop2d43_max_items(pc.simds)) {  // 4-3, lowest latency: one state per wavefront on the two-row fold
+    if (width == 4 && n <= coop2d43_max_items(pc.simds)) {  // 4-3, lowest latency: one state per wavefront on the two-row fold
       const unsigned g = n < 65536 ? unsigned(n) : 65536u;
       if (k == 2) k_jive4_coop<FIELD, 2, 32><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       else k_jive4_coop<FIELD, 4, 32><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
@@ -818,26 +841,27 @@ struct Launch {
   static hipError_t sponge_seg(int width, int bytes, const void* src, size_t per_msg, size_t n, void* out, PermConsts pc,
                                SpongeSeg seg, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (seg.first && seg.last && width == 2 && pc.fold_c && n <= coop2d_max_items(pc.simds)) {  // two messages per wavefront
+    // small batches: the latency kernels, whole messages and segments alike (the state is carried in seg.state)
+    if (width == 2 && n <= coop2d_max_items(pc.simds)) {  // two messages per wavefront
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
-      if (bytes) k_sponge_coop<FIELD, 2, true, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
-      else k_sponge_coop<FIELD, 2, false, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
+      if (bytes) k_sponge_coop<FIELD, 2, true, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
+      else k_sponge_coop<FIELD, 2, false, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
       return hipGetLastError();
     }
-    if (seg.first && seg.last && width == 4 && pc.fold_c && n <= coop2d43_max_items(pc.simds)) {  // one 4-3 message per wavefront
+    if (width == 4 && n <= coop2d43_max_items(pc.simds)) {  // one 4-3 message per wavefront
       const unsigned g = n < 65536 ? unsigned(n) : 65536u;
-      if (bytes) k_sponge_coop<FIELD, 4, true, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
-      else k_sponge_coop<FIELD, 4, false, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
+      if (bytes) k_sponge_coop<FIELD, 4, true, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
+      else k_sponge_coop<FIELD, 4, false, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
       return hipGetLastError();
     }
-    if (seg.first && seg.last && n <= coop_sponge_max_items(pc.simds)) {  // latency path: whole small batches
+    if (n <= coop_sponge_max_items(pc.simds)) {  // four (2-1) / two (4-3) messages per wavefront on the scan
       const size_t groups = width == 2 ? (n + 3) / 4 : (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
-      if (width == 2 && bytes) k_sponge_coop<FIELD, 2, true><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
-      else if (width == 2) k_sponge_coop<FIELD, 2, false><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
-      else if (bytes) k_sponge_coop<FIELD, 4, true><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
-      else k_sponge_coop<FIELD, 4, false><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc);
+      if (width == 2 && bytes) k_sponge_coop<FIELD, 2, true><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
+      else if (width == 2) k_sponge_coop<FIELD, 2, false><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
+      else if (bytes) k_sponge_coop<FIELD, 4, true><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
+      else k_sponge_coop<FIELD, 4, false><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
       return hipGetLastError();
     }
     const size_t l = lds_bytes<A, WIN, 1>(), lp = lds_bytes<A, WIN, 2>();
@@ -858,14 +882,14 @@ struct Launch {
   }
 
   static hipError_t sponge_ragged(int width, const void* msgs, const void* off, size_t n, void* out, PermConsts pc,
-                                  hipStream_t s) {
+                                  const void* order, hipStream_t s) {
     if (!n) return hipSuccess;
     if (width == 2)
       k_sponge_ragged<FIELD><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>((const uint8_t*)msgs, (const uint64_t*)off,
-                                                                                n, (uint4*)out, pc);
+                                                                                n, (uint4*)out, pc, (const uint32_t*)order);
     else
       k_sponge_ragged_pair<FIELD><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(
-          (const uint8_t*)msgs, (const uint64_t*)off, n, (uint4*)out, pc);
+          (const uint8_t*)msgs, (const uint64_t*)off, n, (uint4*)out, pc, (const uint32_t*)order);
     return hipGetLastError();
   }
 
@@ -878,7 +902,7 @@ struct Launch {
   static hipError_t merkle_climb(const void* leaves, const void* index, const void* paths, unsigned depth, size_t n,
                                  void* out, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
-    if (pc.fold_c && n <= coop2d_max_items(pc.simds)) {  // very few paths: two per wavefront on row pairs
+    if (n <= coop2d_max_items(pc.simds)) {  // very few paths: two per wavefront on row pairs
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
       k_merkle_climb_coop<FIELD, 32><<<g, kBlock, 0, s>>>((const uint32_t*)leaves, (const uint64_t*)index,

@@ -95,7 +95,7 @@ struct PermConsts {
   // the instance's round constants in the cooperative kernels' limb layout (F::Coop)
   const uint32_t* coop_c;
   const uint32_t* coop_d;
-  // ... and in the two-row fold layout (F::Fold, coop2d.h); Anemoi-2-1 only (null for width 4)
+  // ... and in the two-row fold layout (F::Fold, coop2d.h); both widths
   const uint32_t* fold_c;
   const uint32_t* fold_d;
   // host-side routing only: SIMDs of the device these tables live on (4 per CU); the automatic cut-offs of the

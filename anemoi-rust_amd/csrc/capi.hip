@@ -418,11 +418,12 @@ int sponge_host(int field, int width, int bytes, const void* src, size_t per_msg
       // Few messages (cannot be cut by message), or long ones (a message chunk of one quantum would be hundreds of
       // MB of staging): feed blocks of at most one quantum of messages segment by segment.
       const size_t blk = count < 2 * quantum ? count : quantum;
-      // (a batch small enough for the row-cooperative sponge is compute-bound by orders of magnitude -- one permutation
-      // per 1.4 ms against 93 bytes of input -- so it goes up in one piece and takes the latency kernel; but only while
-      // "one piece" is small: a few LONG messages (4 096 x 16 MiB, one multi-GiB message) would otherwise need the
-      // whole batch on the device and in pinned staging at once, where the segment path holds three segments)
-      const bool latency_batch = count <= anemoi::coop_sponge_max_items(4 * rt::device_cus(dev)) &&
+      // (a batch small enough for the cooperative sponge kernels is compute-bound by orders of magnitude -- one
+      // permutation per ~1 ms against 93 bytes of input -- so it goes up in one piece; but only while "one piece" is
+      // small: a few LONG messages (4 096 x 16 MiB, one multi-GiB message) would otherwise need the whole batch on the
+      // device and in pinned staging at once, where the segment path holds three segments.  Either way such a batch
+      // takes the latency kernels: since round 5 they absorb segments too, Launch::sponge_seg)
+      const bool latency_batch = count <= anemoi::sponge_latency_max_items(width, 4 * rt::device_cus(dev)) &&
                                  count * per_msg_bytes < kSegmentMinBytes && !segments_forced();
       if (!latency_batch && want_segments(blk, per_msg_bytes, unit) &&
           (count < 2 * quantum || quantum * per_msg_bytes > (size_t(256) << 20))) {
@@ -457,6 +458,48 @@ __global__ void k_assemble4(const uint4* __restrict__ cur, const uint4* __restri
   if (child == pos) v = cur[item * quads + q];
   else v = paths[((item * depth4 + level) * 3 + (child < pos ? child : child - 1)) * quads + q];
   states[t] = v;
+}
+
+// ---- device-side bucketing of a ragged batch (anemoi_hash_bytes_ragged_bucketed_dev) -----------------------------------
+// A wavefront of the ragged sponge kernels runs as many rate-blocks as its LONGEST message; host::ragged_order (the host
+// path's bucketing, host_logic.h) is the specification: messages by descending block count.  Here as a counting sort on
+// the device: histogram of the block counts (clamped to kRaggedBins - 1: longer messages share the first bucket),
+// exclusive scan from the longest bucket down, placement by atomic cursor.  Not stable -- equal block counts land in
+// any order, which costs nothing -- and every digest goes back to its message's own index.
+constexpr int kRaggedBins = 1 << 16;
+__device__ __forceinline__ uint32_t ragged_bin(const uint64_t* __restrict__ off, size_t i, uint32_t block_bytes) {
+  const uint64_t blocks = (off[i + 1] - off[i] + block_bytes - 1) / block_bytes;
+  return uint32_t(kRaggedBins - 1) - uint32_t(blocks < uint64_t(kRaggedBins - 1) ? blocks : uint64_t(kRaggedBins - 1));   // bin 0 = the longest
+}
+__global__ void k_ragged_hist(const uint64_t* __restrict__ off, size_t n, uint32_t block_bytes, uint32_t* __restrict__ bins) {
+  const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&bins[ragged_bin(off, i, block_bytes)], 1u);
+}
+// counts -> first slot of each bin (one workgroup of 1 024 threads, 64 bins each)
+__global__ __launch_bounds__(1024) void k_ragged_scan(uint32_t* __restrict__ bins) {
+  __shared__ uint32_t part[1024];
+  constexpr int PER = kRaggedBins / 1024;
+  uint32_t sum = 0;
+  for (int j = 0; j < PER; j++) sum += bins[threadIdx.x * PER + j];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {   // inclusive scan of the 1 024 partial sums
+    const uint32_t v = threadIdx.x >= unsigned(d) ? part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;
+  for (int j = 0; j < PER; j++) {
+    const uint32_t c = bins[threadIdx.x * PER + j];
+    bins[threadIdx.x * PER + j] = run;
+    run += c;
+  }
+}
+__global__ void k_ragged_place(const uint64_t* __restrict__ off, size_t n, uint32_t block_bytes, uint32_t* __restrict__ bins,
+                               uint32_t* __restrict__ order) {
+  const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) order[atomicAdd(&bins[ragged_bin(off, i, block_bytes)], 1u)] = uint32_t(i);
 }
 
 // anemoi_probe_issue_rate: every lane runs ONE dependent chain of v_mad_u64_u32 -- the instruction that carries the
@@ -694,7 +737,8 @@ int anemoi_get_option(const char* name, long long* value) {
   const int id = anemoi::opt::find(name);
   if (id < 0 || !value) return ANEMOI_ERR_ARG;
   *value = anemoi::opt::get(anemoi::opt::Id(id));
-  g_last_error = anemoi::opt::env_error();   // "" unless an environment value was rejected at start-up
+  // an environment value rejected at start-up is reported here; otherwise the thread's last error text is left alone
+  if (!anemoi::opt::env_error().empty()) g_last_error = anemoi::opt::env_error();
   return ANEMOI_OK;
 }
 
@@ -952,7 +996,32 @@ int anemoi_hash_bytes_ragged_dev(int field, int width, const void* d_msgs, const
   if (n && (!d_out || !d_offsets || !d_msgs)) return ANEMOI_ERR_ARG;
   PermConsts pc;
   if ((rc = get_consts(field, width, &pc))) return rc;
-  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, d_msgs, d_offsets, n, d_out, pc, (hipStream_t)stream));
+  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, d_msgs, d_offsets, n, d_out, pc, nullptr, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+
+size_t anemoi_ragged_scratch_bytes(size_t n) { return (size_t(kRaggedBins) + n) * sizeof(uint32_t); }
+
+int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void* d_msgs, const void* d_offsets, size_t n,
+                                          void* d_out, void* d_scratch, size_t scratch_bytes, void* stream) {
+  int rc = check_instance(field, width);
+  if (rc) return rc;
+  if (n && (!d_out || !d_offsets || !d_msgs || !d_scratch)) return ANEMOI_ERR_ARG;
+  if (n >= (size_t(1) << 32) || scratch_bytes < anemoi_ragged_scratch_bytes(n)) return ANEMOI_ERR_ARG;
+  if (!n) return ANEMOI_OK;
+  PermConsts pc;
+  if ((rc = get_consts(field, width, &pc))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* bins = (uint32_t*)d_scratch;      // kRaggedBins counters, then the order: n message indices
+  uint32_t* order = bins + kRaggedBins;
+  const uint32_t block_bytes = uint32_t(width - 1) * uint32_t(anemoi::field_ops(field)->chunk);   // bytes one permutation absorbs
+  const unsigned grid = unsigned((n + 255) / 256);
+  HIP_TRY(hipMemsetAsync(bins, 0, size_t(kRaggedBins) * sizeof(uint32_t), s));
+  k_ragged_hist<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, block_bytes, bins);
+  k_ragged_scan<<<1, 1024, 0, s>>>(bins);
+  k_ragged_place<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, block_bytes, bins, order);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, d_msgs, d_offsets, n, d_out, pc, order, s));
   return ANEMOI_OK;
 }
 

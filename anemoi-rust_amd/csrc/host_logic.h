@@ -164,7 +164,9 @@ inline std::vector<size_t> ragged_order(const uint64_t* off, size_t n, size_t bl
     hi = key[i] > hi ? key[i] : hi;
   }
   order.resize(n);
-  if (hi - lo < (size_t(1) << 22)) {
+  // (only while the key range is of the batch's order -- span <= 4 n: a 65-message batch with one 390 MB message must not
+  // allocate and prefix-sum four million buckets to order 65 items -- else the comparison sort)
+  if (hi - lo <= 4 * n && hi - lo < (size_t(1) << 22)) {
     std::vector<size_t> start(hi - lo + 2, 0);
     for (size_t i = 0; i < n; i++) start[hi - key[i] + 1]++;          // bucket 0 = the longest messages
     for (size_t b = 1; b < start.size(); b++) start[b] += start[b - 1];

@@ -36,6 +36,11 @@
  * that the FIRST use of a (device, field, width) uploads that instance's constant tables with a blocking
  * copy (not legal inside a stream capture): call anemoi_init() beforehand to get that out of the way.
  * Input and output ranges of a `_dev` Jive call must not overlap (ANEMOI_ERR_ARG).
+ * STREAM CAPTURE: once its instance is initialised, every `_dev` function only launches kernels (a depth-0 tree: one
+ * asynchronous device-to-device copy) on the stream it is handed, so it may be captured into a hipGraph; the options below
+ * are read on the HOST when the call is made, so a graph keeps the kernels chosen at capture time whatever the options
+ * become later (tests/test_gpu_capture.py).  Not capturable: anemoi_init / anemoi_warmup / anemoi_release /
+ * anemoi_probe_issue_rate, anemoi_generic_prepare / _destroy, and every host-pointer function (they copy and wait).
  *
  * OPTIONS: the kernel-selection cut-offs and the test / diagnostic knobs are listed with anemoi_set_option below.
  * Each is read from its environment variable ONCE (first use) and changed afterwards only through the API; no entry
@@ -176,7 +181,9 @@ int anemoi_hash_bytes_batch(int field, int width, const uint8_t *msgs, size_t ms
 
 /* Sponge::hash on n messages of DIFFERENT lengths: message i = bytes [offsets[i], offsets[i+1]) of `msgs`
  * (n + 1 non-decreasing byte offsets; an empty message hashes to the digest of the zero state, as the
- * reference's hash(b"") does).  A wavefront costs what its longest message costs: sort by length for speed. */
+ * reference's hash(b"") does).  Messages may come in any order: a wavefront costs what its longest message costs, so the
+ * library stages them by descending block count and scatters the digests back (an unsorted long-tailed batch costs 1.02 x
+ * the pre-sorted one). */
 int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t *msgs, const uint64_t *offsets, size_t n,
                                    uint64_t *out, int device);
 
@@ -264,9 +271,19 @@ int anemoi_hash_field_dev(int field, int width, const void *d_elems, size_t elem
                           void *stream);
 int anemoi_hash_bytes_dev(int field, int width, const void *d_msgs, size_t msg_len, size_t n, void *d_out,
                           void *stream);
-/* d_offsets: n + 1 uint64 byte offsets into d_msgs (see anemoi_hash_bytes_ragged_batch). */
+/* d_offsets: n + 1 uint64 byte offsets into d_msgs (see anemoi_hash_bytes_ragged_batch).  Messages are processed IN THE
+ * GIVEN ORDER, 64 (Anemoi-2-1) or 32 (4-3) consecutive messages per wavefront, and a wavefront runs as long as its longest
+ * message: right for batches that are already grouped by length; for anything else use the bucketed form below. */
 int anemoi_hash_bytes_ragged_dev(int field, int width, const void *d_msgs, const void *d_offsets, size_t n, void *d_out,
                                  void *stream);
+/* The same on an UNSORTED device-resident batch: the library first orders the messages by descending block count on the
+ * device (a counting sort: histogram, scan, placement -- three small launches on `stream`), runs the ragged kernels in
+ * that order and writes every digest to its message's own index.  d_scratch: anemoi_ragged_scratch_bytes(n) bytes of
+ * device memory the caller owns (65 536 counters + n 32-bit indices), contents undefined afterwards; n < 2^32.  Only
+ * launches and one memset on `stream`: capturable like the other `_dev` functions. */
+size_t anemoi_ragged_scratch_bytes(size_t n);
+int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void *d_msgs, const void *d_offsets, size_t n, void *d_out,
+                                          void *d_scratch, size_t scratch_bytes, void *stream);
 /* d_scratch: at least 2^depth elements; d_root: 1 element; d_leaves is not modified. */
 int anemoi_merkle_root_dev(int field, const void *d_leaves, unsigned depth, void *d_scratch, void *d_root,
                            void *stream);

@@ -683,7 +683,7 @@ struct Walk {
       }
       // ragged: two lanes, one message ends two blocks before the other (its state runs on unobserved)
       std::vector<uint64_t> off{0, ch - 3, ch - 3 + 3 * ch};
-      lane_case("k_sponge_ragged", 2, [&] { k_sponge_ragged<FIELD>(bytes.data(), off.data(), 2, out.data(), pc); });
+      lane_case("k_sponge_ragged", 2, [&] { k_sponge_ragged<FIELD>(bytes.data(), off.data(), 2, out.data(), pc, nullptr); });
       lane_case("k_merkle_climb depth 3", 1, [&] { k_merkle_climb<FIELD>(in.data(), index.data(), st.data(), 3, 1, out.data(), pc); });
     }
     // ---- Anemoi-4-3: a state per lane (the form no launcher uses, kept compiling) and per lane PAIR (the shipped one)
@@ -714,7 +714,7 @@ struct Walk {
         }
       }
       std::vector<uint64_t> off{0, 2, 2 + 9 * ch};
-      lane_case("k_sponge_ragged_pair", 4, [&] { k_sponge_ragged_pair<FIELD>(bytes.data(), off.data(), 2, out.data(), pc); });
+      lane_case("k_sponge_ragged_pair", 4, [&] { k_sponge_ragged_pair<FIELD>(bytes.data(), off.data(), 2, out.data(), pc, nullptr); });
     }
     // ---- instances given at run time: NUM_COLUMNS = 1 .. 16, constants through k_generic_prepare as the product does
     {
@@ -760,24 +760,58 @@ struct Walk {
       w.template coop_case<LPI>("k_merkle_climb_coop<" + t + " depth 3", [&](const PermConsts& pc) {
         k_merkle_climb_coop<FIELD, LPI>(in.data(), index.data(), st.data(), 3, 1, out.data(), pc);
       });
-      w.template coop_case<LPI>("k_sponge_coop<2,bytes," + t, [&](const PermConsts& pc) {
-        k_sponge_coop<FIELD, 2, true, LPI>(bytes.data(), 3 * ch + 5, 1, out.data(), pc);
-      });
-      w.template coop_case<LPI>("k_sponge_coop<2,elements," + t, [&](const PermConsts& pc) {
-        k_sponge_coop<FIELD, 2, false, LPI>(in.data(), 4, 1, out.data(), pc);
-      });
+      std::vector<uint32_t> carry(64 * 4 * F::N, 0);
+      {   // a whole message, and the two halves of a segmented run (the state carried as ABI elements)
+        const size_t len = 3 * ch + 5, head_len = 2 * ch;
+        const SpongeSeg whole{nullptr, 0, len, 1, 1}, head{carry.data(), 0, len, 1, 0}, tail{carry.data(), 2, len, 0, 1};
+        w.template coop_case<LPI>("k_sponge_coop<2,bytes," + t + " whole", [&](const PermConsts& pc) {
+          k_sponge_coop<FIELD, 2, true, LPI>(bytes.data(), len, 1, out.data(), pc, whole);
+        });
+        w.template coop_case<LPI>("k_sponge_coop<2,bytes," + t + " first segment", [&](const PermConsts& pc) {
+          k_sponge_coop<FIELD, 2, true, LPI>(bytes.data(), head_len, 1, out.data(), pc, head);
+        });
+        w.template coop_case<LPI>("k_sponge_coop<2,bytes," + t + " last segment", [&](const PermConsts& pc) {
+          k_sponge_coop<FIELD, 2, true, LPI>(bytes.data(), len - head_len, 1, out.data(), pc, tail);
+        });
+      }
+      {
+        const SpongeSeg whole{nullptr, 0, 4, 1, 1}, tail{carry.data(), 2, 4, 0, 1};
+        w.template coop_case<LPI>("k_sponge_coop<2,elements," + t + " whole", [&](const PermConsts& pc) {
+          k_sponge_coop<FIELD, 2, false, LPI>(in.data(), 4, 1, out.data(), pc, whole);
+        });
+        w.template coop_case<LPI>("k_sponge_coop<2,elements," + t + " last segment", [&](const PermConsts& pc) {
+          k_sponge_coop<FIELD, 2, false, LPI>(in.data(), 2, 1, out.data(), pc, tail);
+        });
+      }
     }
     {
       Walk w(4);
       w.template coop_case<LPI>("k_jive4_coop<2," + t, [&](const PermConsts& pc) { k_jive4_coop<FIELD, 2, LPI>(in.data(), out.data(), 1, pc); });
       w.template coop_case<LPI>("k_jive4_coop<4," + t, [&](const PermConsts& pc) { k_jive4_coop<FIELD, 4, LPI>(in.data(), out.data(), 1, pc); });
       w.template coop_case<LPI>("k_permutation_coop<4," + t, [&](const PermConsts& pc) { k_permutation_coop<FIELD, 4, LPI>(st.data(), 1, pc); });
-      w.template coop_case<LPI>("k_sponge_coop<4,bytes," + t, [&](const PermConsts& pc) {
-        k_sponge_coop<FIELD, 4, true, LPI>(bytes.data(), 7 * ch + 5, 1, out.data(), pc);
-      });
-      w.template coop_case<LPI>("k_sponge_coop<4,elements," + t, [&](const PermConsts& pc) {
-        k_sponge_coop<FIELD, 4, false, LPI>(in.data(), 7, 1, out.data(), pc);
-      });
+      std::vector<uint32_t> carry(64 * 4 * F::N, 0);
+      {
+        const size_t len = 7 * ch + 5, head_len = 3 * ch;   // 8 elements: two full rate blocks, a third with padding
+        const SpongeSeg whole{nullptr, 0, len, 1, 1}, head{carry.data(), 0, len, 1, 0}, tail{carry.data(), 3, len, 0, 1};
+        w.template coop_case<LPI>("k_sponge_coop<4,bytes," + t + " whole", [&](const PermConsts& pc) {
+          k_sponge_coop<FIELD, 4, true, LPI>(bytes.data(), len, 1, out.data(), pc, whole);
+        });
+        w.template coop_case<LPI>("k_sponge_coop<4,bytes," + t + " first segment", [&](const PermConsts& pc) {
+          k_sponge_coop<FIELD, 4, true, LPI>(bytes.data(), head_len, 1, out.data(), pc, head);
+        });
+        w.template coop_case<LPI>("k_sponge_coop<4,bytes," + t + " last segment", [&](const PermConsts& pc) {
+          k_sponge_coop<FIELD, 4, true, LPI>(bytes.data(), len - head_len, 1, out.data(), pc, tail);
+        });
+      }
+      {
+        const SpongeSeg whole{nullptr, 0, 7, 1, 1}, tail{carry.data(), 3, 7, 0, 1};
+        w.template coop_case<LPI>("k_sponge_coop<4,elements," + t + " whole", [&](const PermConsts& pc) {
+          k_sponge_coop<FIELD, 4, false, LPI>(in.data(), 7, 1, out.data(), pc, whole);
+        });
+        w.template coop_case<LPI>("k_sponge_coop<4,elements," + t + " last segment", [&](const PermConsts& pc) {
+          k_sponge_coop<FIELD, 4, false, LPI>(in.data(), 4, 1, out.data(), pc, tail);
+        });
+      }
     }
   }
 };

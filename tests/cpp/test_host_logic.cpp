@@ -156,9 +156,14 @@ static void test_ragged_order() {
   for (int trial = 0; trial < 300; trial++) {
     const size_t n = rnd() % 700, per_wave = (rnd() % 2) ? 64 : 32, block = 31 * (1 + rnd() % 3);
     std::vector<uint64_t> off(n + 1, 0);
-    const unsigned shape = rnd() % 4;   // 0: equal lengths, 1: already sorted, 2: long-tailed, 3: uniform
+    // 0: equal lengths, 1: already sorted, 2: long-tailed, 3: uniform, 4: one HUGE message among small ones -- its block
+    // count stretches the key range far beyond 4 n, so the comparison-sort branch orders the batch (shapes 2 and 3 take
+    // the counting sort whenever n is large enough for their range)
+    const unsigned shape = rnd() % 5;
+    const size_t huge_at = n ? rnd() % n : 0;
     for (size_t i = 0; i < n; i++) {
       uint64_t len = shape == 0 ? 500 : shape == 2 ? (rnd() % 16 == 0 ? rnd() % 20000 : rnd() % 300) : rnd() % 3000;
+      if (shape == 4) len = i == huge_at ? 390000000ull + rnd() % 1000 : rnd() % 400;
       off[i + 1] = off[i] + len;
     }
     if (shape == 1) {
@@ -201,7 +206,30 @@ static void test_ragged_order() {
       }
       CHECK(cost(order) <= cost(ident));
       CHECK(shape != 0);   // equal lengths are never reordered
+      if (shape == 4) CHECK(order[0] == huge_at);
+      // what the host path does with it (capi.hip: messages staged in `order`, digests scattered back): slot j of the
+      // staged batch holds message order[j], its digest goes to out[order[j]] -- every message's digest lands at its own
+      // index exactly once, whatever the order
+      std::vector<uint64_t> staged_len(n), out(n, ~0ull);
+      for (size_t j = 0; j < n; j++) staged_len[j] = off[order[j] + 1] - off[order[j]];
+      for (size_t j = 0; j < n; j++) {
+        CHECK(out[order[j]] == ~0ull);
+        out[order[j]] = staged_len[j] * 2654435761ull + 7;      // stand-in for "the digest of a message of this length"
+      }
+      for (size_t i = 0; i < n; i++) CHECK(out[i] == (off[i + 1] - off[i]) * 2654435761ull + 7);
     }
+  }
+  // both sort branches on the SAME keys give the same stable order: a batch whose key range is just inside / just outside 4 n
+  for (int wide = 0; wide < 2; wide++) {
+    const size_t n = 200, block = 31;
+    std::vector<uint64_t> off(n + 1, 0);
+    for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + block * ((i * 37) % 50) + (wide && i == 17 ? block * 100000ull : 0);
+    const std::vector<size_t> order = ragged_order(off.data(), n, block, 64);
+    CHECK(order.size() == n);
+    std::vector<size_t> ref(n);
+    for (size_t i = 0; i < n; i++) ref[i] = i;
+    std::stable_sort(ref.begin(), ref.end(), [&](size_t a, size_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+    CHECK(order == ref);
   }
 }
 

@@ -55,9 +55,11 @@ LANE_FAMILIES = ["k_permutation<2>", "k_permutation<2,sbox_only>", "k_jive<2,2>"
                  "k_permutation_pair<sbox_only>", "k_jive_pair<2>", "k_jive_pair<4>", "k_sponge_pair<bytes> whole",
                  "k_sponge_pair<bytes> first segment", "k_sponge_pair<bytes> last segment", "k_sponge_pair<elements> whole",
                  "k_sponge_pair<elements> first segment", "k_sponge_pair<elements> last segment", "k_sponge_ragged_pair"]
-COOP_FAMILIES = ["k_jive2_coop<%s>", "k_permutation_coop<2,%s>", "k_merkle_climb_coop<%s> depth 3", "k_sponge_coop<2,bytes,%s>",
-                 "k_sponge_coop<2,elements,%s>", "k_jive4_coop<2,%s>", "k_jive4_coop<4,%s>", "k_permutation_coop<4,%s>",
-                 "k_sponge_coop<4,bytes,%s>", "k_sponge_coop<4,elements,%s>"]
+COOP_FAMILIES = ["k_jive2_coop<%s>", "k_permutation_coop<2,%s>", "k_merkle_climb_coop<%s> depth 3", "k_jive4_coop<2,%s>",
+                 "k_jive4_coop<4,%s>", "k_permutation_coop<4,%s>"]
+for _w in (2, 4):
+    COOP_FAMILIES += ["k_sponge_coop<%d,bytes,%%s> %s" % (_w, part) for part in ("whole", "first segment", "last segment")]
+    COOP_FAMILIES += ["k_sponge_coop<%d,elements,%%s> %s" % (_w, part) for part in ("whole", "last segment")]
 
 
 def test_the_walk_covers_every_kernel_family(logs):

@@ -1,0 +1,90 @@
+"""The `_dev` API under stream capture (include/anemoi_mi355x.h: "`_dev` functions ... enqueue asynchronously and do not
+synchronise -- except that the FIRST use of a (device, field, width) uploads that instance's constant tables with a
+blocking copy (not legal inside a stream capture): call anemoi_init() beforehand").
+
+After anemoi_init, three calls are captured into ONE hipGraph on a side stream (torch.cuda.graph is plumbing: the
+library only ever sees the hipStream_t it is handed):
+  * anemoi_merkle_root_dev, depth 16 Jubjub: a chain of 16 launches that picks three different kernels by level size --
+    lane-private (2^15, 2^14 nodes), the row-cooperative scan (8 192, 4 096) and the two-row fold (2 048 ... 1);
+  * anemoi_hash_bytes_dev (BN-254 Anemoi-4-3, 700 messages of 200 bytes: the two-row fold sponge);
+  * anemoi_jive_compress_k_dev (BLS12-381, 20 000 states: the lane-private throughput kernel).
+The graph is replayed three times on FRESH inputs written into the captured buffers, every output compared with the
+oracle.  Then the cut-offs are changed through anemoi_set_option -- which would send the same sizes to other kernels --
+and the captured graph must still give the right bits: capture froze the kernel CHOICE made at capture time (the
+routing runs on the host), not the options, and every kernel of a family computes the same function.  A call made
+AFTER the change, outside the graph, takes the new route and agrees as well.
+"""
+import numpy as np
+import pytest
+
+from conftest import FIELD_IDS
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
+    import torch
+    import anemoi_amd as A
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(21)
+    jub, bn, bls = FIELD_IDS.index("jubjub"), FIELD_IDS.index("bn_254"), FIELD_IDS.index("bls12_381")
+    depth, nmsg, mlen, nst = 16, 700, 200, 20000
+    for f, w in ((jub, 2), (bn, 4), (bls, 2)):
+        assert A.lib.anemoi_init(0, f, w) == 0          # constant tables up front: nothing but launches below
+
+    def fresh():
+        leaves = rng.integers(0, 1 << 60, size=(1 << depth, 4), dtype=np.uint64)      # limbs < 2^60: canonical elements
+        msgs = rng.integers(0, 256, size=(nmsg, mlen), dtype=np.uint8)
+        states = rng.integers(0, 1 << 60, size=(nst, 2, 6), dtype=np.uint64)
+        return leaves, msgs, states
+
+    def i64(a):
+        return torch.from_numpy(a.view(np.int64).reshape(-1)).to(dev)
+
+    leaves, msgs, states = fresh()
+    d_leaves, d_msgs, d_states = i64(leaves), torch.from_numpy(msgs.reshape(-1)).to(dev), i64(states)
+    d_scratch = torch.empty((1 << depth) * 4, dtype=torch.int64, device=dev)
+    d_root = torch.zeros(4, dtype=torch.int64, device=dev)
+    d_dig = torch.zeros(nmsg * 4, dtype=torch.int64, device=dev)
+    d_out = torch.zeros(nst * 6, dtype=torch.int64, device=dev)
+
+    def enqueue(stream):
+        s = stream.cuda_stream
+        assert A.lib.anemoi_merkle_root_dev(jub, d_leaves.data_ptr(), depth, d_scratch.data_ptr(), d_root.data_ptr(), s) == 0
+        assert A.lib.anemoi_hash_bytes_dev(bn, 4, d_msgs.data_ptr(), mlen, nmsg, d_dig.data_ptr(), s) == 0
+        assert A.lib.anemoi_jive_compress_k_dev(bls, 2, 2, d_states.data_ptr(), d_out.data_ptr(), nst, s) == 0
+
+    def check(what):
+        torch.cuda.synchronize()
+        got_root = d_root.cpu().numpy().view(np.uint64)
+        assert (got_root == oracle.merkle_root(jub, leaves, depth)).all(), what + ": Merkle root"
+        got_dig = d_dig.cpu().numpy().view(np.uint64).reshape(nmsg, 4)
+        assert (got_dig == oracle.hash_bytes_batch(bn, 4, msgs, threads=8)).all(), what + ": sponge digests"
+        got_out = d_out.cpu().numpy().view(np.uint64).reshape(nst, 6)
+        assert (got_out == oracle.compress_batch(bls, 2, states, threads=8)).all(), what + ": Jive outputs"
+
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        enqueue(torch.cuda.current_stream())
+    for replay in range(3):
+        if replay:
+            leaves, msgs, states = fresh()
+            d_leaves.copy_(i64(leaves)), d_msgs.copy_(torch.from_numpy(msgs.reshape(-1)).to(dev)), d_states.copy_(i64(states))
+        d_root.zero_(), d_dig.zero_(), d_out.zero_()
+        graph.replay()
+        check("replay %d" % replay)
+
+    # other cut-offs: the same sizes would now take other kernels (no fold kernels, no scan kernels: everything lane-private)
+    with A.options(coop2d_max=0, coop2d43_max=0, coop4_max=0, coop43_max=0, coop_sponge_max=0):
+        leaves, msgs, states = fresh()
+        d_leaves.copy_(i64(leaves)), d_msgs.copy_(torch.from_numpy(msgs.reshape(-1)).to(dev)), d_states.copy_(i64(states))
+        d_root.zero_(), d_dig.zero_(), d_out.zero_()
+        graph.replay()                                   # still the kernels chosen at capture time
+        check("replay after the options changed")
+        d_root.zero_(), d_dig.zero_(), d_out.zero_()
+        enqueue(torch.cuda.current_stream())             # a direct call takes the new route
+        check("direct call on the new route")
+    d_root.zero_(), d_dig.zero_(), d_out.zero_()
+    graph.replay()
+    check("replay after the options were restored")

@@ -310,6 +310,48 @@ def test_ragged_batch_of_messages_of_different_lengths(A, oracle):
                                                 out.ctypes.data_as(_lib._u64p), 0) == -3
 
 
+def test_unsorted_device_resident_ragged_batch_is_bucketed_on_the_device(A, oracle):
+    """anemoi_hash_bytes_ragged_bucketed_dev: the device-side counting sort by block count in front of the ragged kernels
+    (the device-resident counterpart of the host path's bucketing).  A long-tailed UNSORTED batch -- most messages short,
+    one in sixteen long, some empty, n not a multiple of a wavefront -- both widths: every digest at ITS message's index
+    equals the oracle's hash of that message alone and the in-order entry point's result; too little scratch is
+    refused."""
+    import torch
+    from anemoi_amd import _lib
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    s = torch.cuda.current_stream().cuda_stream
+    for field, width, n in (("bn_254", 4, 1237), ("jubjub", 2, 2100), ("bls12_381", 2, 130), ("pallas", 4, 1)):
+        fid, inst = FIELD_IDS.index(field), A.Anemoi(field, width)
+        L = inst.limbs
+        lens = [int(rng.integers(2000, 9000)) if rng.integers(0, 16) == 0 else int(rng.integers(0, 260)) for _ in range(n)]
+        lens[n // 2] = 0
+        msgs = [rng.integers(0, 256, size=k, dtype=np.uint8).tobytes() for k in lens]
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens, dtype=np.uint64)
+        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8)
+        d_blob, d_offs = torch.from_numpy(blob.copy()).to(dev), torch.from_numpy(offs.view(np.int64)).to(dev)
+        d_out = torch.zeros(n * L, dtype=torch.int64, device=dev)
+        d_ref = torch.zeros(n * L, dtype=torch.int64, device=dev)
+        need = A.lib.anemoi_ragged_scratch_bytes(n)
+        assert need == (65536 + n) * 4
+        d_scr = torch.empty(need, dtype=torch.uint8, device=dev)
+        assert A.lib.anemoi_init(0, fid, width) == 0
+        args = (fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n, d_out.data_ptr(), d_scr.data_ptr())
+        assert A.lib.anemoi_hash_bytes_ragged_bucketed_dev(*args, need - 1, s) == -3
+        assert A.lib.anemoi_hash_bytes_ragged_bucketed_dev(*args, need, s) == 0
+        assert A.lib.anemoi_hash_bytes_ragged_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n, d_ref.data_ptr(), s) == 0
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().view(np.uint64).reshape(n, L)
+        assert (got == d_ref.cpu().numpy().view(np.uint64).reshape(n, L)).all(), (field, width)
+        for i in list(range(0, n, 37)) + [n // 2, n - 1]:
+            assert (got[i] == oracle.hash_bytes(fid, width, msgs[i])).all(), (field, width, i, lens[i])
+        order = d_scr.cpu().numpy()[65536 * 4:].view(np.uint32)
+        assert sorted(order.tolist()) == list(range(n))                       # a permutation ...
+        blocks = [-(-lens[i] // ((width - 1) * inst.chunk)) for i in order]
+        assert all(a >= b for a, b in zip(blocks, blocks[1:]))                 # ... by descending block count
+
+
 def test_pinned_caller_buffers_are_used_directly(A, oracle):
     """Host buffers that are already pinned (here: pinned torch tensors) skip the staging copy; results are the
     same bits, also when only one side is pinned and across several chunks."""

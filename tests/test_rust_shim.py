@@ -92,7 +92,7 @@ def test_parameter_types_agree_across_header_ctypes_and_rust():
     rust = rust_extern_types(open(LIB_RS).read())
     import ctypes
     TYPE_TABLE = type_table()
-    ret_table = {"int": (ctypes.c_int, "c_int"), "const char *": (ctypes.c_char_p, "*const c_char")}
+    ret_table = {"int": (ctypes.c_int, "c_int"), "const char *": (ctypes.c_char_p, "*const c_char"), "size_t": (ctypes.c_size_t, "usize")}
     for name, ret, params in funcs:
         cty_args, cty_ret = _lib._SIGS[name]
         r_args, r_ret = rust[name]

@@ -126,9 +126,22 @@ if "ragged" in sys.argv or len(sys.argv) == 1:
         res.append(a.elapsed_time(b))
     resident = median(res[1:])
     want = d_o.cpu().numpy().view(np.uint64).reshape(-1, 4)
-    del d_b, d_off, d_o
+    d_scr = torch.empty(A.lib.anemoi_ragged_scratch_bytes(nm), dtype=torch.uint8, device="cuda:0")
+    res = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        assert A.lib.anemoi_hash_bytes_ragged_bucketed_dev(f3, 4, d_b.data_ptr(), d_off.data_ptr(), nm, d_o.data_ptr(), d_scr.data_ptr(),
+                                                           d_scr.numel(), s.cuda_stream) == 0
+        b.record(s)
+        torch.cuda.synchronize()
+        res.append(a.elapsed_time(b))
+    assert (d_o.cpu().numpy().view(np.uint64).reshape(-1, 4) == want).all()
+    bucketed = median(res[1:])
+    del d_b, d_off, d_o, d_scr
     torch.cuda.empty_cache()
-    print("ragged batch (2^19 messages, %.0f MiB, BN-254 4-3): device-resident kernel %.1f ms" % (blob.size / 2**20, resident))
+    print("ragged batch (2^19 messages, %.0f MiB, BN-254 4-3): device-resident kernel, messages in the given (unsorted) order %.1f ms; "
+          "bucketed on the device (anemoi_hash_bytes_ragged_bucketed_dev) %.1f ms" % (blob.size / 2**20, resident, bucketed))
     for mode in ("pinned", "direct"):
         A.set_option("host_staging", mode)
         ts = []
@@ -173,7 +186,35 @@ if "ragged" in sys.argv or len(sys.argv) == 1:
     print("long-tailed ragged batch (2^19 messages, %.0f MiB): pre-sorted %.1f ms, unsorted %.1f ms -> %.3f x"
           % (blob.size / 2**20, res["pre-sorted by length"], res["unsorted (library buckets)"],
              res["unsorted (library buckets)"] / res["pre-sorted by length"]))
-    del blob, offs, s_blob, s_offs
+    # the same two batches DEVICE-RESIDENT: in the given order (anemoi_hash_bytes_ragged_dev) and bucketed on the device
+    # (anemoi_hash_bytes_ragged_bucketed_dev: counting sort by block count, digests scattered back)
+    def dev_ms(fn):
+        ts = []
+        for _ in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(s)
+            assert fn() == 0
+            b.record(s)
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return median(ts[1:])
+    d_o = torch.zeros(nm * 4, dtype=torch.int64, device="cuda:0")
+    d_scr = torch.empty(A.lib.anemoi_ragged_scratch_bytes(nm), dtype=torch.uint8, device="cuda:0")
+    dres = {}
+    for label, b_, o_ in (("pre-sorted", s_blob, s_offs), ("unsorted", blob, offs)):
+        d_b, d_f = torch.from_numpy(b_).to("cuda:0"), torch.from_numpy(o_.view(np.int64)).to("cuda:0")
+        dres[label, "in order"] = dev_ms(lambda: A.lib.anemoi_hash_bytes_ragged_dev(f3, 4, d_b.data_ptr(), d_f.data_ptr(), nm, d_o.data_ptr(), s.cuda_stream))
+        ref = d_o.clone()
+        dres[label, "bucketed"] = dev_ms(lambda: A.lib.anemoi_hash_bytes_ragged_bucketed_dev(
+            f3, 4, d_b.data_ptr(), d_f.data_ptr(), nm, d_o.data_ptr(), d_scr.data_ptr(), d_scr.numel(), s.cuda_stream))
+        assert torch.equal(ref, d_o)
+        del d_b, d_f
+    print("  device-resident: pre-sorted, in order %.1f ms | unsorted, in order %.1f ms | unsorted, bucketed on the device %.1f ms "
+          "(%.3f x the pre-sorted one) | pre-sorted, bucketed %.1f ms"
+          % (dres["pre-sorted", "in order"], dres["unsorted", "in order"], dres["unsorted", "bucketed"],
+             dres["unsorted", "bucketed"] / dres["pre-sorted", "in order"], dres["pre-sorted", "bucketed"]))
+    del blob, offs, s_blob, s_offs, d_o, d_scr
+    torch.cuda.empty_cache()
 
 # 2^22 depth-24 authentication paths (Jubjub; 3.4 GB of host memory) through anemoi_merkle_verify_batch
 if "verify" in sys.argv or len(sys.argv) == 1:

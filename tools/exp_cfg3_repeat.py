@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Why is the FIRST config-3 launch of a process 46 % slower in KERNEL time (rocprofv3: 487 ms against 333 ms)?
 Experiment: warm the same kernel with a small batch first / touch the message buffer first / neither.
-    python tools/exp_cfg3_repeat.py [warm_kernel] [touch_msgs]
+    python tools/exp_cfg3_repeat.py [warm_kernel] [touch_msgs] [warm=<messages>] [api_warmup]
+api_warmup: anemoi_warmup(0, bn_254, 4) first -- the library's own cure (round 5).
 """
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +24,12 @@ def timed(n, ln):
     torch.cuda.synchronize()
     return round(a.elapsed_time(b), 1)
 
+if "api_warmup" in sys.argv:
+    import time
+    lib.anemoi_warmup.argtypes = [ci, ci, ci]
+    t0 = time.perf_counter()
+    assert lib.anemoi_warmup(0, 2, 4) == 0
+    print("anemoi_warmup(0, bn_254, 4): %.1f ms" % (1e3 * (time.perf_counter() - t0)))
 if "warm_kernel" in sys.argv:
     print("warm-up: 2^15 messages of 93 bytes (the same kernel):", timed(1 << 15, 93), "ms, again", timed(1 << 15, 93))
 for a in sys.argv[1:]:
