@@ -51,7 +51,7 @@ constexpr int kBlock = 64;  // one wavefront per workgroup: the LDS window table
 #endif
 
 // build_config.h: ANEMOI_HOLD_INPUTS_MAX_NL = 13 (k_jive 2-1 keeps the feed-forward sum in VGPRs up to this many limbs),
-// ANEMOI_WIN = 3 (3 LDS entries per lane -> 13 waves per CU)
+// ANEMOI_WIN = 3 (3 LDS entries per lane -> 13 waves per CU; LABNOTES.md section 3.3)
 template <int N>
 struct KernelCfg {
   static constexpr int WIN = ANEMOI_WIN;  // sliding-window bits -> 2^(WIN-1) odd powers per lane in LDS

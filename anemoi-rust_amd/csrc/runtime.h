@@ -341,7 +341,7 @@ inline int shard_parts(int ndev) {
 
 // Runs `body(part, device, first, count)` for every part: one host thread per DEVICE, which works through its
 // parts (part i belongs to device i % ndev) one after the other -- two big batches side by side on one GPU
-// only slow each other down.  The first failure (lowest part) is reported with its
+// only slow each other down (LABNOTES.md section 7, item 2).  The first failure (lowest part) is reported with its
 // thread's error text.
 template <class Body>
 int run_parts(int parts, int ndev, size_t n, Body body) {
