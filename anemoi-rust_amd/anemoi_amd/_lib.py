@@ -67,7 +67,7 @@ _SIGS = {
     "anemoi_init": ([_int, _int, _int], _int),
     "anemoi_release": ([_int], _int),
     "anemoi_warmup": ([_int, _int, _int], _int),
-    "anemoi_probe_issue_rate": ([_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)], _int),
+    "anemoi_probe_issue_rate": ([_int] + [ctypes.POINTER(ctypes.c_double)] * 4, _int),
     "anemoi_set_option": ([ctypes.c_char_p, ctypes.c_longlong], _int),
     "anemoi_get_option": ([ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)], _int),
     "anemoi_permutation_batch": ([_int, _int, _u64p, _sz, _int], _int),
@@ -151,13 +151,14 @@ def warmup(field, width, device=ALL_DEVICES):
 
 
 def probe_issue_rate(device=0):
-    """(lane multiply-adds per second, shader clock in GHz) of a full grid of dependent v_mad_u64_u32 chains on `device`
-    (anemoi_probe_issue_rate): what this box delivers of the instruction the throughput kernels are made of."""
-    rate, ghz = ctypes.c_double(0), ctypes.c_double(0)
-    rc = lib.anemoi_probe_issue_rate(device, ctypes.byref(rate), ctypes.byref(ghz))
+    """anemoi_probe_issue_rate on `device`: (lane multiply-adds per second, shader clock in GHz) of a full grid of bare
+    dependent v_mad_u64_u32 chains, then the same two figures for a chain of the generated BLS12-381 squaring -- what
+    this box delivers of the instruction, and of the instruction mix, the throughput kernels are made of."""
+    v = [ctypes.c_double(0) for _ in range(4)]
+    rc = lib.anemoi_probe_issue_rate(device, *[ctypes.byref(x) for x in v])
     if rc != 0:
         raise AnemoiError(rc, lib.anemoi_last_error().decode())
-    return rate.value, ghz.value
+    return tuple(x.value for x in v)
 
 
 def release(device=ALL_DEVICES):

@@ -526,6 +526,29 @@ __global__ __launch_bounds__(64) void k_issue_probe(uint64_t* __restrict__ rec, 
 }
 constexpr int kProbeMadsPerIter = 64;
 
+// ... and the same grid running what the throughput kernels are MADE of: a chain of the generated BLS12-381 squaring
+// (mont29_asm_gen.h: 260 multiply-adds among 345 instructions, the mix and the power draw of the headline kernel, which
+// is 80 % squarings).  The chip holds a different clock under this mix than under bare multiply-adds, and boxes differ in
+// how much: this is the probe a kernel's rate should be read against.
+__global__ __launch_bounds__(64) void k_issue_probe_sqr(uint64_t* __restrict__ rec, int iters) {
+  asm volatile("v_mov_b32 v160, 0" ::: "v160");
+  using L = anemoi::FieldC<0>::R30;
+  uint32_t a[L::NL];
+#pragma unroll
+  for (int i = 0; i < L::NL; i++) a[i] = (threadIdx.x * 2654435761u + i * 40503u + blockIdx.x) & ((1u << 30) - 1);
+  a[L::NL - 1] &= 0xffff;   // below p: every later value is a squaring's result, below 2p
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+#pragma nounroll
+  for (int i = 0; i < iters; i++) anemoi::AsmMont<0, 30>::sqr(a);
+  const uint64_t c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    rec[3 * blockIdx.x] = t1 - t0;
+    rec[3 * blockIdx.x + 1] = c1 - c0;
+  }
+  if (a[0] == 0x7fffffffu) rec[3 * blockIdx.x + 2] = a[1];   // keeps the chain alive; a limb is below 2^30
+}
+constexpr int kProbeMadsPerSquaring = 260;   // 13 x 14 / 2 products + 13 x 13 reduction (tools/gen_asm_mul.py; buildinfo.py)
+
 // Root / retained tree over arity^depth host leaves, on one device or sharded into subtrees over all
 // devices (the only cross-GPU data: one subtree root per part, finished on the first device).
 int merkle_host(TreeShape ts, const uint64_t* leaves, unsigned depth, uint64_t* root, uint64_t* tree, int device) {
@@ -674,8 +697,9 @@ int anemoi_warmup(int device, int field, int width) {
   return ANEMOI_OK;
 }
 
-int anemoi_probe_issue_rate(int device, double* lane_mad_per_s, double* shader_clock_ghz) {
-  if (!lane_mad_per_s || !shader_clock_ghz) return ANEMOI_ERR_ARG;
+int anemoi_probe_issue_rate(int device, double* lane_mad_per_s, double* shader_clock_ghz, double* sqr_lane_mad_per_s,
+                            double* sqr_shader_clock_ghz) {
+  if (!lane_mad_per_s || !shader_clock_ghz || !sqr_lane_mad_per_s || !sqr_shader_clock_ghz) return ANEMOI_ERR_ARG;
   int ndev = 0, rc = rt::physical_devices(&ndev);
   if (rc) return rc;
   if (device < 0 || device >= ndev) {
@@ -683,32 +707,39 @@ int anemoi_probe_issue_rate(int device, double* lane_mad_per_s, double* shader_c
     return ANEMOI_ERR_DEVICE;
   }
   return with_lane(device, [&](Lane& ln) -> int {
-    const int simds = 4 * rt::device_cus(device), grid = 3 * simds, iters = 60000;   // ~20 ms
+    const int simds = 4 * rt::device_cus(device), grid = 3 * simds;
     int r = ln.slot[0].d_out.reserve(size_t(grid) * 3 * sizeof(uint64_t));
     if (r) return r;
     uint64_t* rec = (uint64_t*)ln.slot[0].d_out.p;
-    hipEvent_t a = nullptr, b = nullptr;
-    HIP_TRY(hipEventCreate(&a));
-    HIP_TRY(hipEventCreate(&b));
-    k_issue_probe<<<grid, 64, 0, ln.s_k>>>(rec, iters / 8);   // untimed: the clock the timed launch sees is a loaded one
-    (void)hipEventRecord(a, ln.s_k);
-    k_issue_probe<<<grid, 64, 0, ln.s_k>>>(rec, iters);
-    (void)hipEventRecord(b, ln.s_k);
-    hipError_t e = hipEventSynchronize(b);
-    float ms = 0;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
-    std::vector<uint64_t> h(size_t(grid) * 3);
-    if (e == hipSuccess) e = hipMemcpy(h.data(), rec, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    HIP_TRY(e);
-    std::vector<double> ghz;
-    for (int i = 0; i < grid; i++)
-      if (h[3 * i]) ghz.push_back(double(h[3 * i + 1]) / double(h[3 * i]) * 0.1);   // cycles per 10 ns tick
-    std::sort(ghz.begin(), ghz.end());
-    *shader_clock_ghz = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
-    *lane_mad_per_s = double(grid) * 64.0 * double(iters) * kProbeMadsPerIter / (double(ms) * 1e-3);
-    return ANEMOI_OK;
+    // one probe: an untimed launch first (the clock the timed launch sees is a loaded one), then ~20 ms timed
+    auto run = [&](bool squarings, int iters, int mads_per_iter, double* rate, double* clock) -> int {
+      hipEvent_t a = nullptr, b = nullptr;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      if (squarings) k_issue_probe_sqr<<<grid, 64, 0, ln.s_k>>>(rec, iters / 8);
+      else k_issue_probe<<<grid, 64, 0, ln.s_k>>>(rec, iters / 8);
+      (void)hipEventRecord(a, ln.s_k);
+      if (squarings) k_issue_probe_sqr<<<grid, 64, 0, ln.s_k>>>(rec, iters);
+      else k_issue_probe<<<grid, 64, 0, ln.s_k>>>(rec, iters);
+      (void)hipEventRecord(b, ln.s_k);
+      hipError_t e = hipEventSynchronize(b);
+      float ms = 0;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+      std::vector<uint64_t> h(size_t(grid) * 3);
+      if (e == hipSuccess) e = hipMemcpy(h.data(), rec, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+      HIP_TRY(e);
+      std::vector<double> ghz;
+      for (int i = 0; i < grid; i++)
+        if (h[3 * i]) ghz.push_back(double(h[3 * i + 1]) / double(h[3 * i]) * 0.1);   // cycles per 10 ns tick
+      std::sort(ghz.begin(), ghz.end());
+      *clock = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
+      *rate = double(grid) * 64.0 * double(iters) * double(mads_per_iter) / (double(ms) * 1e-3);
+      return ANEMOI_OK;
+    };
+    if ((r = run(false, 60000, kProbeMadsPerIter, lane_mad_per_s, shader_clock_ghz))) return r;
+    return run(true, 11000, kProbeMadsPerSquaring, sqr_lane_mad_per_s, sqr_shader_clock_ghz);
   });
 }
 

@@ -34,9 +34,10 @@ Also printed in the same JSON line:
   alu           v_mad_u64_u32 lane-operations per second / (1024 SIMDs x 16 lanes x clock), and -- so that a slow BOX and a slow
                 BUILD can be told apart from the line alone -- the same quantity for a fixed probe kernel run right after the
                 timed steps (anemoi_probe_issue_rate: a full grid, three wavefronts per SIMD, of dependent v_mad_u64_u32 chains):
-                `probe_lane_mad_per_s`, the clock the chip held during it (`probe_clock_GHz`, s_memtime / s_memrealtime), and
-                `frac_of_probe` = the kernel's multiply-add rate / the probe's.  The boxes of the pool differ by several per cent
-                under this load; frac_of_probe does not.
+                `probe_lane_mad_per_s`, the clock the chip held during it (`probe_clock_GHz`, s_memtime / s_memrealtime), and the
+                same for a chain of the generated squaring, whose instruction mix is the kernel's (`probe_sqr_*`);
+                `frac_of_sqr_probe` = the kernel's multiply-add rate / that probe's.  The boxes of the pool differ by several
+                per cent under this load; frac_of_sqr_probe does not.
   cpu_baseline  the pinned C oracle ("port": same algorithm, u64-limb CIOS like arkworks) timed on a
                 bounded sample on this box's host cores, all threads and one thread (rank 0, N = 1 only),
                 with the CPU model; plus a probe for a Rust toolchain that could time the reference itself.
@@ -245,8 +246,8 @@ def main():
     elapsed = max_over_ranks(elapsed, dist, dev if backend == "nccl" else None)
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
     # what THIS GPU delivers of the kernels' instruction right now (outside the timed steps, the chip still under load)
-    probe_rate, probe_ghz = A.probe_issue_rate(local_rank)
-    probe_min = -max_over_ranks(-probe_rate, dist, dev if backend == "nccl" else None)   # the slowest rank's GPU
+    probe_rate, probe_ghz, probe_sqr_rate, probe_sqr_ghz = A.probe_issue_rate(local_rank)
+    probe_min = -max_over_ranks(-probe_sqr_rate, dist, dev if backend == "nccl" else None)   # the slowest rank's GPU
 
     # ---- the timed output against the oracle goldens of this exact batch (every rank checks its shard)
     with open(os.path.join(ROOT, "tests", "golden", "cfg_full.json")) as f:
@@ -320,12 +321,16 @@ def main():
                     # can overstate; at the maximum clock it cannot, on any box of the pool.
                     "peak_lane_mad_per_s": peak_lane_ops, "clock_GHz": MAX_GHZ, "clock_source": "maximum engine clock",
                     "frac": lane_mad_per_s / peak_lane_ops,
-                    # box or build?  The fixed probe kernel on THIS GPU, right after the timed steps: its multiply-add rate,
-                    # the shader clock it ran at, and the benchmarked kernel's rate as a fraction of it.  A slower box moves
-                    # `value` and `probe_lane_mad_per_s` together; a slower build moves `frac_of_probe`.
+                    # box or build?  Two fixed probe kernels on THIS GPU, right after the timed steps: bare dependent
+                    # multiply-add chains (`probe_*`: what the instruction can do here, and the clock the chip holds for it)
+                    # and a chain of the generated BLS12-381 squaring (`probe_sqr_*`: the instruction MIX and power draw of the
+                    # benchmarked kernel, which is 80 % squarings).  A slower box moves `value` and `probe_sqr_lane_mad_per_s`
+                    # together; a slower build moves `frac_of_sqr_probe` -- the figure to compare across boxes and rounds.
                     "probe_lane_mad_per_s": probe_rate, "probe_clock_GHz": probe_ghz,
                     "probe_frac_of_peak": probe_rate / peak_lane_ops, "frac_of_probe": lane_mad_per_s / probe_rate,
-                    "probe_lane_mad_per_s_min_over_ranks": probe_min,
+                    "probe_sqr_lane_mad_per_s": probe_sqr_rate, "probe_sqr_clock_GHz": probe_sqr_ghz,
+                    "frac_of_sqr_probe": lane_mad_per_s / probe_sqr_rate,
+                    "probe_sqr_lane_mad_per_s_min_over_ranks": probe_min,
                     # secondary: the same ratio at the clock of the committed profile run (GRBM_GUI_ACTIVE / duration
                     # on THAT box); indicative only
                     "frac_at_profile_clock": (lane_mad_per_s / (SIMDS * LANES_PER_CLK * prof_clock * 1e9)) if prof_clock else None,

@@ -108,12 +108,17 @@ int anemoi_release(int device);
 int anemoi_warmup(int device, int field, int width);
 
 /* ---- diagnostics ----------------------------------------------------------------------------
- * What this GPU delivers right now of the one instruction that carries the throughput kernels: a full grid (three
- * wavefronts per SIMD) of dependent v_mad_u64_u32 chains for ~20 ms on `device`.  *lane_mad_per_s = lane multiply-adds
- * per second (the 16-lanes-per-clock ceiling is SIMDs x 16 x clock); *shader_clock_ghz = the clock the chip held while
- * it ran (s_memtime / s_memrealtime, median over the workgroups).  bench.py reports both beside its line, so that a
- * slow box and a slow build can be told apart (boxes of one pool differ by several per cent under this load). */
-int anemoi_probe_issue_rate(int device, double *lane_mad_per_s, double *shader_clock_ghz);
+ * What this GPU delivers right now of the instruction that carries the throughput kernels, two fixed kernels of ~20 ms
+ * each on a full grid (three wavefronts per SIMD) of `device`:
+ *   (1) bare dependent v_mad_u64_u32 chains      -> *lane_mad_per_s (lane multiply-adds per second; the ceiling at 16
+ *       lanes per clock is SIMDs x 16 x clock) and *shader_clock_ghz, the clock the chip held meanwhile (s_memtime /
+ *       s_memrealtime, median over the workgroups);
+ *   (2) a chain of the generated BLS12-381 squaring (260 multiply-adds among 345 instructions: the instruction mix and
+ *       power draw of the headline kernel)       -> *sqr_lane_mad_per_s, *sqr_shader_clock_ghz.
+ * bench.py reports them beside its line, so that a slow box and a slow build can be told apart: boxes of one pool differ
+ * by several per cent under this load, a kernel's rate as a fraction of probe (2) does not. */
+int anemoi_probe_issue_rate(int device, double *lane_mad_per_s, double *shader_clock_ghz, double *sqr_lane_mad_per_s,
+                            double *sqr_shader_clock_ghz);
 
 /* ---- options --------------------------------------------------------------------------------
  * anemoi_set_option(name, value): value -1 = automatic (the default).  `name` is the option name or its environment

@@ -56,6 +56,13 @@ macro_rules! impl_mi355x {
             assert!(STATE_WIDTH == $width && DIGEST_SIZE == 1);
 
             impl $inst {
+                /// Once at start-up, for a service that cares about the duration of its FIRST large call: uploads this
+                /// instance's constant tables to every GPU and runs each of its throughput kernels once on a small batch
+                /// (~15 ms per GPU; include/anemoi_mi355x.h anemoi_warmup).  Changes no result.
+                pub fn mi355x_warmup() {
+                    check(unsafe { ffi::anemoi_warmup(ffi::ANEMOI_ALL_DEVICES, $field_id, $width) });
+                }
+
                 /// n states of STATE_WIDTH elements -> n x (STATE_WIDTH / 2) elements.
                 pub fn compress_batch(states: &[Felt]) -> Vec<Felt> {
                     Self::compress_k_batch(states, 2)

@@ -172,7 +172,7 @@ int main(int argc, char** argv) {
     auto mb4 = I::merge_batch(pairs4);
     for (size_t i = 0; i < pairs4.size(); i++) EXPECT(mb4[i] == I::merge(pairs4[i]), "merge_batch 4-3 item");
   }
-  // The five symbols the Rust patch binds (integration/rust/reference-patch/mi355x.rs), called the way the patch calls
+  // The symbols the Rust patch binds (integration/rust/reference-patch/mi355x.rs), called the way the patch calls
   // them: `&[Felt]` as one contiguous buffer of L u64 limbs per element cast to `*const u64` / `*mut u64`, lengths as
   // size_t, at the patch's small-batch boundary MI355X_MIN_BATCH = 32 and one item either side of it.  Every item must
   // equal the single-item trait function (what the CPU branch of the patch computes below the boundary).
@@ -180,6 +180,9 @@ int main(int argc, char** argv) {
     using I = AnemoiBls12_381_2_1;
     using J = AnemoiBn254_4_3;
     static_assert(sizeof(I::F) == 6 * 8 && alignof(I::F) == 8 && sizeof(J::F) == 4 * 8, "Felt = L u64 limbs, as the patch asserts");
+    // (and the sixth: `H::mi355x_warmup()` = anemoi_warmup(ANEMOI_ALL_DEVICES, FIELD, WIDTH), once at start-up; no result changes)
+    EXPECT(anemoi_warmup(ANEMOI_ALL_DEVICES, ANEMOI_BLS12_381, 2) == 0 && anemoi_warmup(ANEMOI_ALL_DEVICES, ANEMOI_BN_254, 4) == 0, "anemoi_warmup");
+    EXPECT(anemoi_warmup(0, 99, 2) == ANEMOI_ERR_FIELD && anemoi_warmup(0, ANEMOI_BN_254, 3) == ANEMOI_ERR_WIDTH, "anemoi_warmup rejects");
     for (size_t n : {size_t(31), size_t(32), size_t(33)}) {
       std::vector<I::F> st(2 * n), out(n);
       for (size_t i = 0; i < st.size(); i++) st[i] = I::hash(std::vector<uint8_t>(1 + i % 7, uint8_t(i))).to_elements()[0];

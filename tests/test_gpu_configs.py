@@ -485,7 +485,7 @@ def test_bench_four_ranks_share_one_gpu_over_gloo(A):
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 4 and line["verified"]["ranks"] == 4 and line["verified"]["sha256_of_all_outputs"] is True
     assert line["config"]["parallelism"] == "shard4" and line["config"]["batch_per_gpu"] == 1 << 21
-    assert 0 < line["alu"]["probe_lane_mad_per_s_min_over_ranks"] <= line["alu"]["probe_lane_mad_per_s"] * 1.5
+    assert 0 < line["alu"]["probe_sqr_lane_mad_per_s_min_over_ranks"] <= line["alu"]["probe_sqr_lane_mad_per_s"] * 1.5
     bad = _bench_two_ranks({"ANEMOI_BENCH_BACKEND": "gloo", "ANEMOI_BENCH_TEST_CORRUPT_RANK": "3"}, ranks=4)
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
     assert "rank 3" in bad.stderr

@@ -129,7 +129,7 @@ def test_patch_uses_existing_symbols_and_covers_all_instances(params):
     ext = rust_externs(open(LIB_RS).read())
     used = re.findall(r"ffi::(anemoi_[a-z0-9_]+)\(([^;]*?)\)\s*\}\)", patch, flags=re.S)
     assert {u[0] for u in used} == {"anemoi_jive_compress_k_batch", "anemoi_hash_bytes_batch", "anemoi_hash_field_batch",
-                                    "anemoi_merge_batch", "anemoi_permutation_batch"}
+                                    "anemoi_merge_batch", "anemoi_permutation_batch", "anemoi_warmup"}
     for name, args in used:
         nargs = len([a for a in args.split(",") if a.strip()])
         assert ext[name] == nargs, (name, nargs, ext[name])
@@ -143,7 +143,7 @@ def test_patch_uses_existing_symbols_and_covers_all_instances(params):
         assert int(re.search(r"pub const %s: c_int = (\d+);" % const, lib).group(1)) == FIELD_IDS.index(field)
         assert int(limbs) == params[field]["u64_limbs"] and int(width) == (2 if shape == "2_1" else 4)
         assert struct.endswith("_" + shape)
-    for fn in ("compress_batch", "compress_k_batch", "hash_batch", "hash_field_batch", "merge_batch"):
+    for fn in ("compress_batch", "compress_k_batch", "hash_batch", "hash_field_batch", "merge_batch", "mi355x_warmup"):
         assert "pub fn %s(" % fn in patch
     assert "size_of::<Felt>() == 8 * $limbs" in patch and "align_of::<Felt>() == 8" in patch
 
