@@ -711,12 +711,12 @@ int anemoi_probe_issue_rate(int device, double* lane_mad_per_s, double* shader_c
     int r = ln.slot[0].d_out.reserve(size_t(grid) * 3 * sizeof(uint64_t));
     if (r) return r;
     uint64_t* rec = (uint64_t*)ln.slot[0].d_out.p;
-    // one probe: an untimed launch first (the clock the timed launch sees is a loaded one), then ~20 ms timed
+    // one probe: an untimed launch first (the clock the timed launch sees is a loaded one), then the timed one
     auto run = [&](bool squarings, int iters, int mads_per_iter, double* rate, double* clock) -> int {
       hipEvent_t a = nullptr, b = nullptr;
       HIP_TRY(hipEventCreate(&a));
       HIP_TRY(hipEventCreate(&b));
-      if (squarings) k_issue_probe_sqr<<<grid, 64, 0, ln.s_k>>>(rec, iters / 8);
+      if (squarings) k_issue_probe_sqr<<<grid, 64, 0, ln.s_k>>>(rec, iters / 4);
       else k_issue_probe<<<grid, 64, 0, ln.s_k>>>(rec, iters / 8);
       (void)hipEventRecord(a, ln.s_k);
       if (squarings) k_issue_probe_sqr<<<grid, 64, 0, ln.s_k>>>(rec, iters);
@@ -738,8 +738,10 @@ int anemoi_probe_issue_rate(int device, double* lane_mad_per_s, double* shader_c
       *rate = double(grid) * 64.0 * double(iters) * double(mads_per_iter) / (double(ms) * 1e-3);
       return ANEMOI_OK;
     };
-    if ((r = run(false, 60000, kProbeMadsPerIter, lane_mad_per_s, shader_clock_ghz))) return r;
-    return run(true, 11000, kProbeMadsPerSquaring, sqr_lane_mad_per_s, sqr_shader_clock_ghz);
+    if ((r = run(false, 60000, kProbeMadsPerIter, lane_mad_per_s, shader_clock_ghz))) return r;   // ~20 ms
+    // ~200 ms (after ~50 ms untimed): under this mix the chip's clock settles over tens of milliseconds, and a 20 ms
+    // sample of it wanders by +-1.5 % from run to run on one box (profiles/r05/bench_probe_across_boxes.txt)
+    return run(true, 110000, kProbeMadsPerSquaring, sqr_lane_mad_per_s, sqr_shader_clock_ghz);
   });
 }
 

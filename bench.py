@@ -246,7 +246,9 @@ def main():
     elapsed = max_over_ranks(elapsed, dist, dev if backend == "nccl" else None)
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
     # what THIS GPU delivers of the kernels' instruction right now (outside the timed steps, the chip still under load)
-    probe_rate, probe_ghz, probe_sqr_rate, probe_sqr_ghz = A.probe_issue_rate(local_rank)
+    # (median of three runs of the probes: the squaring probe's rate wanders by +-1 % from run to run on one box)
+    probes = sorted((A.probe_issue_rate(local_rank) for _ in range(3)), key=lambda p: p[2])
+    probe_rate, probe_ghz, probe_sqr_rate, probe_sqr_ghz = probes[1]
     probe_min = -max_over_ranks(-probe_sqr_rate, dist, dev if backend == "nccl" else None)   # the slowest rank's GPU
 
     # ---- the timed output against the oracle goldens of this exact batch (every rank checks its shard)

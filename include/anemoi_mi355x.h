@@ -108,8 +108,8 @@ int anemoi_release(int device);
 int anemoi_warmup(int device, int field, int width);
 
 /* ---- diagnostics ----------------------------------------------------------------------------
- * What this GPU delivers right now of the instruction that carries the throughput kernels, two fixed kernels of ~20 ms
- * each on a full grid (three wavefronts per SIMD) of `device`:
+ * What this GPU delivers right now of the instruction that carries the throughput kernels, two fixed kernels (~20 ms and
+ * ~200 ms) on a full grid (three wavefronts per SIMD) of `device`:
  *   (1) bare dependent v_mad_u64_u32 chains      -> *lane_mad_per_s (lane multiply-adds per second; the ceiling at 16
  *       lanes per clock is SIMDs x 16 x clock) and *shader_clock_ghz, the clock the chip held meanwhile (s_memtime /
  *       s_memrealtime, median over the workgroups);
