@@ -4,8 +4,8 @@ blocking copy (not legal inside a stream capture): call anemoi_init() beforehand
 
 After anemoi_init, three calls are captured into ONE hipGraph on a side stream (torch.cuda.graph is plumbing: the
 library only ever sees the hipStream_t it is handed):
-  * anemoi_merkle_root_dev, depth 16 Jubjub: a chain of 16 launches that picks three different kernels by level size --
-    lane-private (2^15, 2^14 nodes), the row-cooperative scan (8 192, 4 096) and the two-row fold (2 048 ... 1);
+  * anemoi_merkle_root_dev, depth 15 Jubjub: a chain of 15 launches that picks three different kernels by level size --
+    lane-private (2^14 nodes), the row-cooperative scan (8 192, 4 096) and the two-row fold (2 048 ... 1);
   * anemoi_hash_bytes_dev (BN-254 Anemoi-4-3, 700 messages of 200 bytes: the two-row fold sponge);
   * anemoi_jive_compress_k_dev (BLS12-381, 20 000 states: the lane-private throughput kernel).
 The graph is replayed three times on FRESH inputs written into the captured buffers, every output compared with the
@@ -28,7 +28,7 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(21)
     jub, bn, bls = FIELD_IDS.index("jubjub"), FIELD_IDS.index("bn_254"), FIELD_IDS.index("bls12_381")
-    depth, nmsg, mlen, nst = 16, 700, 200, 20000
+    depth, nmsg, mlen, nst = 15, 700, 200, 20000
     for f, w in ((jub, 2), (bn, 4), (bls, 2)):
         assert A.lib.anemoi_init(0, f, w) == 0          # constant tables up front: nothing but launches below
 
