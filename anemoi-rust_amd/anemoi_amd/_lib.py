@@ -68,6 +68,12 @@ _SIGS = {
     "anemoi_release": ([_int], _int),
     "anemoi_warmup": ([_int, _int, _int], _int),
     "anemoi_probe_issue_rate": ([_int] + [ctypes.POINTER(ctypes.c_double)] * 4, _int),
+    "anemoi_clock_sampler_bytes": ([], _sz),
+    "anemoi_clock_sampler_start_dev": ([_vp, _sz, ctypes.c_uint, ctypes.c_uint, _vp], _int),
+    "anemoi_clock_sampler_stop_dev": ([_vp, _vp], _int),
+    "anemoi_clock_stamp_dev": ([_vp, _vp], _int),
+    "anemoi_clock_sampler_read": ([_vp, _sz, ctypes.c_ulonglong, ctypes.c_ulonglong] + [ctypes.POINTER(ctypes.c_double)] * 3
+                                  + [ctypes.POINTER(_int)], _int),
     "anemoi_set_option": ([ctypes.c_char_p, ctypes.c_longlong], _int),
     "anemoi_get_option": ([ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)], _int),
     "anemoi_permutation_batch": ([_int, _int, _u64p, _sz, _int], _int),
@@ -159,6 +165,44 @@ def probe_issue_rate(device=0):
     if rc != 0:
         raise AnemoiError(rc, lib.anemoi_last_error().decode())
     return tuple(x.value for x in v)
+
+
+class ClockSampler:
+    """The shader clock the chip holds WHILE work runs on `work_stream` (anemoi_clock_sampler_*; torch is plumbing: device
+    memory and streams).  start() before the work is enqueued, finish() after it is enqueued -- everything is ordered on
+    the device, the host never waits in between -- then read() once the device is idle:
+        cs = ClockSampler(device); cs.start(work_stream); ...enqueue work...; cs.finish(work_stream); torch.cuda.synchronize()
+        mean_ghz, min_ghz, max_ghz, groups = cs.read()"""
+
+    def __init__(self, device, period_us=2000, max_ms=120000):
+        import torch
+        self.torch, self.period_us, self.max_ms = torch, period_us, max_ms
+        self.bytes = lib.anemoi_clock_sampler_bytes()
+        self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=device)
+        self.stamps = torch.zeros(2, dtype=torch.int64, device=device)
+        self.side, self.third = torch.cuda.Stream(device), torch.cuda.Stream(device)
+
+    def start(self, work_stream):
+        _check(lib.anemoi_clock_sampler_start_dev(self.buf.data_ptr(), self.bytes, self.period_us, self.max_ms, self.side.cuda_stream))
+        _check(lib.anemoi_clock_stamp_dev(self.stamps.data_ptr(), work_stream.cuda_stream))
+
+    def finish(self, work_stream):
+        """second stamp behind the work, then the stop ordered behind THAT on a stream of its own (the sampler's stream never
+        ends by itself, so nothing may wait for it before the stop is queued)"""
+        _check(lib.anemoi_clock_stamp_dev(self.stamps.data_ptr() + 8, work_stream.cuda_stream))
+        ev = self.torch.cuda.Event()
+        ev.record(work_stream)
+        self.third.wait_event(ev)
+        _check(lib.anemoi_clock_sampler_stop_dev(self.buf.data_ptr(), self.third.cuda_stream))
+
+    def read(self):
+        host = self.buf.cpu().numpy()
+        st = self.stamps.cpu().numpy().view(np.uint64)
+        v = [ctypes.c_double(0) for _ in range(3)]
+        g = ctypes.c_int(0)
+        _check(lib.anemoi_clock_sampler_read(host.ctypes.data, self.bytes, int(st[0]), int(st[1]), ctypes.byref(v[0]),
+                                             ctypes.byref(v[1]), ctypes.byref(v[2]), ctypes.byref(g)))
+        return v[0].value, v[1].value, v[2].value, g.value
 
 
 def release(device=ALL_DEVICES):

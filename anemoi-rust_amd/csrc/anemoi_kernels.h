@@ -154,14 +154,14 @@ ANEMOI_KERNEL void k_permutation(uint4* __restrict__ states, size_t n, PermConst
 }
 
 // out[i] = sum_{j<k} in[i + c*j] + perm(in)[i + c*j], c = W/k  (k = 2: c = W/2 outputs; k = 4: 1 output)
+// One block of 64 states (the work of one workgroup = one wavefront).
 template <int FIELD, int W, int K>
-ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n,
-                                                 PermConsts pc) {
+__device__ __forceinline__ void jive_block(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n, const PermConsts& pc,
+                                           size_t block, uint4* lds) {
   using F = FieldC<FIELD>;
   using A = ArithFor<FIELD>;
   constexpr int WIN = KernelCfg<F::N>::WIN, PER = W * A::NABI / 4, C = W / K;
-  extern __shared__ uint4 lds[];
-  const size_t blk0 = size_t(blockIdx.x) * kBlock;
+  const size_t blk0 = block * kBlock;
   const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
   block_load<PER>(lds, in, blk0, cnt);
   typename A::Fe st[W], sum[C];
@@ -205,6 +205,37 @@ ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out,
   static_for<0, C>([&](auto i) { lds_put<A>(lds, threadIdx.x * C + i, sum[i]); });
   block_store<C * A::NABI / 4>(lds, out, blk0, cnt);
 }
+
+template <int FIELD, int W, int K>
+ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n,
+                                                 PermConsts pc) {
+  extern __shared__ uint4 lds[];
+  jive_block<FIELD, W, K>(in, out, n, pc, blockIdx.x, lds);
+}
+
+#if ANEMOI_AB_BUILD
+// RECORDED NEGATIVE (laboratory builds only; tools/exp_jive_queue.py, profiles/r05/jive_work_queue_not_adopted.txt): the
+// same, the blocks handed out by a counter -- a workgroup takes the next block when it has finished one.  The thought:
+// the sampled clocks of the XCDs differ by 2-5 % under this load and kernel time x the SLOWEST sampled clock is the same
+// 228.4 Mcycles on every box, as if the launch waited for the slowest XCD to work off its statically dealt eighth; with a
+// queue the faster XCDs would take more.  Measured in one process: 100.00 against 100.24 ms at 2^20, 200.56 against
+// 200.27 at 2^21 -- nothing.  Whatever makes the slowest sampled clock the right one, it is not static dealing.
+// `queue[0]` must be 0 at launch; grid = the resident workgroups of the device.
+template <int FIELD, int W, int K>
+ANEMOI_KERNEL void k_jive_queue(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n, PermConsts pc,
+                                uint32_t* __restrict__ queue) {
+  extern __shared__ uint4 lds[];
+  const uint32_t nblocks = uint32_t((n + kBlock - 1) / kBlock);
+  for (;;) {
+    uint32_t b = 0;
+    if (threadIdx.x == 0) b = atomicAdd(queue, 1u);
+    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    if (b >= nblocks) break;
+    jive_block<FIELD, W, K>(in, out, n, pc, b, lds);
+    __syncthreads();   // the staging area is reused by the next block
+  }
+}
+#endif  // ANEMOI_AB_BUILD
 
 // One chunk of a byte message -> internal Montgomery element (from_le_bytes_mod_order + the
 // reference's padding rule: a SHORT last chunk gets a 0x01 byte appended; hasher.rs:36-57).
@@ -696,6 +727,10 @@ struct FieldOps {
   // one small launch of every THROUGHPUT kernel of (field, width) -- Jive, permutation, sponge over bytes and over
   // elements -- on n items of zeros (d_buf: n states, d_out: n states of room): anemoi_warmup
   hipError_t (*warmup)(int width, void* d_buf, void* d_out, size_t n, PermConsts pc, hipStream_t s);
+#if ANEMOI_AB_BUILD
+  // Jive 2-1 with the blocks handed out by a counter (d_queue[0] = 0 at launch); `wgs` resident workgroups
+  hipError_t (*jive_queue)(const void* d_in, void* d_out, size_t n, PermConsts pc, uint32_t* d_queue, unsigned wgs, hipStream_t s);
+#endif
 };
 
 enum KernelKind { kKindPermutation = 0, kKindJive = 1, kKindSponge = 2, kKindConvert = 3, kKindExpAlpha = 4 };
@@ -982,6 +1017,13 @@ struct Launch {
     return hipGetLastError();
   }
 
+#if ANEMOI_AB_BUILD
+  static hipError_t jive_queue(const void* in, void* out, size_t n, PermConsts pc, uint32_t* queue, unsigned wgs, hipStream_t s) {
+    k_jive_queue<FIELD, 2, 2><<<wgs, kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc, queue);
+    return hipGetLastError();
+  }
+#endif
+
   template <class K>
   static size_t resident_items(K kernel, size_t lds, int items_per_wg, int num_cus) {
     int nb = 0;
@@ -1012,7 +1054,11 @@ struct Launch {
     static const FieldOps o{F::L64,       F::kChunk,    F::kRounds21,        F::kRounds43, F::kG, F::kAlpha, F::kName,
                             host_consts,  permutation,  jive,                sponge,       sponge_seg,   sponge_ragged, mont_convert,
                             merkle_climb, generic_permutation, generic_jive, generic_sponge, exp_alpha,
-                            generic_prepare, generic_stride<A>(), wave_items, warmup};
+                            generic_prepare, generic_stride<A>(), wave_items, warmup
+#if ANEMOI_AB_BUILD
+                            , jive_queue
+#endif
+    };
     return &o;
   }
 };

@@ -549,6 +549,47 @@ __global__ __launch_bounds__(64) void k_issue_probe_sqr(uint64_t* __restrict__ r
 }
 constexpr int kProbeMadsPerSquaring = 260;   // 13 x 14 / 2 products + 13 x 13 reduction (tools/gen_asm_mul.py; buildinfo.py)
 
+// ---- the shader clock WHILE other work runs (anemoi_clock_sampler_*) ---------------------------------------------------
+// kSamplerGroups single-wavefront workgroups (consecutive workgroups land on consecutive XCDs) sit beside whatever the
+// caller launches afterwards -- one wave slot and a handful of registers each, asleep between samples -- and log
+// (s_memrealtime, s_memtime) every `period`: the 100 MHz wall clock and the shader-cycle counter.  Between two wall-clock
+// stamps of the caller's own stream (anemoi_clock_stamp_dev) that is the clock the chip HELD under the caller's kernels,
+// per XCD: the one quantity that differs from box to box under this load (profiles/r05/bench_probe_across_boxes.txt)
+// and that a process cannot otherwise read.  Every workgroup ends when the stop flag is set, when its log is full, or
+// after max_ms -- whichever comes first.
+constexpr int kSamplerGroups = 16, kSamplerMaxRecords = 4096;
+struct SamplerGroup {
+  uint32_t count, xcc;
+  uint64_t rec[kSamplerMaxRecords][2];
+};
+struct SamplerBuf {
+  uint32_t stop, groups;
+  uint64_t reserved;
+  SamplerGroup g[kSamplerGroups];
+};
+__global__ __launch_bounds__(64) void k_clock_sampler(SamplerBuf* buf, uint32_t period_ticks, uint64_t max_ticks) {
+  if (threadIdx.x) return;
+  SamplerGroup& g = buf->g[blockIdx.x];
+  g.xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 7u;   // XCC_ID
+  const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
+  uint64_t next = t_begin;
+  uint32_t n = 0;
+  for (;;) {
+    const uint64_t t = __builtin_amdgcn_s_memrealtime();
+    const bool last = __hip_atomic_load(&buf->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || t - t_begin > max_ticks;
+    if (t >= next || last) {
+      g.rec[n][0] = __builtin_amdgcn_s_memrealtime();
+      g.rec[n][1] = __builtin_amdgcn_s_memtime();
+      n++;
+      next += period_ticks;
+    }
+    if (last || n >= uint32_t(kSamplerMaxRecords)) break;
+    __builtin_amdgcn_s_sleep(100);   // ~6 400 cycles: the sampler takes an issue slot every few microseconds
+  }
+  g.count = n;
+}
+__global__ void k_clock_stamp(uint64_t* out) { *out = __builtin_amdgcn_s_memrealtime(); }
+
 // Root / retained tree over arity^depth host leaves, on one device or sharded into subtrees over all
 // devices (the only cross-GPU data: one subtree root per part, finished on the first device).
 int merkle_host(TreeShape ts, const uint64_t* leaves, unsigned depth, uint64_t* root, uint64_t* tree, int device) {
@@ -743,6 +784,67 @@ int anemoi_probe_issue_rate(int device, double* lane_mad_per_s, double* shader_c
     // sample of it wanders by +-1.5 % from run to run on one box (profiles/r05/bench_probe_across_boxes.txt)
     return run(true, 110000, kProbeMadsPerSquaring, sqr_lane_mad_per_s, sqr_shader_clock_ghz);
   });
+}
+
+size_t anemoi_clock_sampler_bytes(void) { return sizeof(SamplerBuf); }
+
+int anemoi_clock_sampler_start_dev(void* d_buf, size_t bytes, unsigned period_us, unsigned max_ms, void* stream) {
+  if (!d_buf || bytes < sizeof(SamplerBuf) || (uintptr_t)d_buf % 8 || period_us < 10 || max_ms < 1 || max_ms > 600000) return ANEMOI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(d_buf, 0, offsetof(SamplerBuf, g), s));                    // stop = 0
+  for (int i = 0; i < kSamplerGroups; i++)                                            // count = 0 of every group
+    HIP_TRY(hipMemsetAsync(&((SamplerBuf*)d_buf)->g[i], 0, 8, s));
+  k_clock_sampler<<<kSamplerGroups, 64, 0, s>>>((SamplerBuf*)d_buf, period_us * 100u, uint64_t(max_ms) * 100000ull);
+  HIP_TRY(hipGetLastError());
+  return ANEMOI_OK;
+}
+
+int anemoi_clock_sampler_stop_dev(void* d_buf, void* stream) {
+  if (!d_buf) return ANEMOI_ERR_ARG;
+  HIP_TRY(hipMemsetAsync(d_buf, 1, sizeof(uint32_t), (hipStream_t)stream));           // stop != 0
+  return ANEMOI_OK;
+}
+
+int anemoi_clock_stamp_dev(void* d_u64, void* stream) {
+  if (!d_u64 || (uintptr_t)d_u64 % 8) return ANEMOI_ERR_ARG;
+  k_clock_stamp<<<1, 1, 0, (hipStream_t)stream>>>((uint64_t*)d_u64);
+  HIP_TRY(hipGetLastError());
+  return ANEMOI_OK;
+}
+
+int anemoi_clock_sampler_read(const void* h_buf, size_t bytes, unsigned long long t0, unsigned long long t1, double* ghz_mean,
+                              double* ghz_min, double* ghz_max, int* groups_used) {
+  if (!h_buf || bytes < sizeof(SamplerBuf) || !ghz_mean || !ghz_min || !ghz_max || !groups_used || t1 <= t0) return ANEMOI_ERR_ARG;
+  const SamplerBuf* b = (const SamplerBuf*)h_buf;
+  double sum = 0, lo = 1e30, hi = 0;
+  int used = 0;
+  for (int i = 0; i < kSamplerGroups; i++) {
+    const SamplerGroup& g = b->g[i];
+    if (g.count < 2 || g.count > uint32_t(kSamplerMaxRecords)) continue;
+    // the samples inside [t0, t1]; the clock of every interval between two of them; the mean of the middle 80 % of the
+    // intervals (the cycle counter of an XCD occasionally jumps: one sampler workgroup then reads 8 % high and its
+    // neighbour 8 % low over half a second -- profiles/r05/clock_sampler_across_boxes.txt -- and a jump spoils ONE interval)
+    std::vector<double> iv;
+    for (uint32_t k = 1; k < g.count; k++) {
+      if (g.rec[k - 1][0] < t0 || g.rec[k][0] > t1 || g.rec[k][0] <= g.rec[k - 1][0]) continue;
+      iv.push_back(double(g.rec[k][1] - g.rec[k - 1][1]) / double(g.rec[k][0] - g.rec[k - 1][0]) * 0.1);   // cycles per 10 ns tick
+    }
+    if (iv.size() < 5) continue;
+    std::sort(iv.begin(), iv.end());
+    const size_t cut = iv.size() / 10;
+    double acc = 0;
+    for (size_t k = cut; k < iv.size() - cut; k++) acc += iv[k];
+    const double ghz = acc / double(iv.size() - 2 * cut);
+    sum += ghz, lo = ghz < lo ? ghz : lo, hi = ghz > hi ? ghz : hi;
+    used++;
+  }
+  *groups_used = used;
+  if (!used) {
+    *ghz_mean = *ghz_min = *ghz_max = 0.0;
+    return ANEMOI_OK;
+  }
+  *ghz_mean = sum / used, *ghz_min = lo, *ghz_max = hi;
+  return ANEMOI_OK;
 }
 
 int anemoi_release(int device) {
@@ -1000,6 +1102,19 @@ int anemoi_jive_compress_k_dev(int field, int width, int k, const void* d_in, vo
   return ANEMOI_OK;
 }
 
+#if ANEMOI_AB_BUILD
+// laboratory builds only (not in the header): Jive 2-1 with a work queue; d_queue = one uint32 owned by the caller
+int anemoi_x_jive_queue_dev(int field, const void* d_in, void* d_out, size_t n, void* d_queue, unsigned wgs, void* stream) {
+  int rc = check_instance(field, 2);
+  if (rc) return rc;
+  PermConsts pc;
+  if ((rc = get_consts(field, 2, &pc))) return rc;
+  HIP_TRY(hipMemsetAsync(d_queue, 0, 4, (hipStream_t)stream));
+  HIP_TRY(anemoi::field_ops(field)->jive_queue(d_in, d_out, n, pc, (uint32_t*)d_queue, wgs, (hipStream_t)stream));
+  return ANEMOI_OK;
+}
+#endif
+
 int anemoi_hash_field_dev(int field, int width, const void* d_elems, size_t elems_per_msg, size_t n, void* d_out,
                           void* stream) {
   int rc = check_instance(field, width);
@@ -1040,7 +1155,8 @@ int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void* d_ms
   int rc = check_instance(field, width);
   if (rc) return rc;
   if (n && (!d_out || !d_offsets || !d_msgs || !d_scratch)) return ANEMOI_ERR_ARG;
-  if (n >= (size_t(1) << 32) || scratch_bytes < anemoi_ragged_scratch_bytes(n)) return ANEMOI_ERR_ARG;
+  if (n >= (size_t(1) << 32) || scratch_bytes < anemoi_ragged_scratch_bytes(n) || (uintptr_t)d_scratch % sizeof(uint32_t))
+    return ANEMOI_ERR_ARG;   // (the scratch is an array of 32-bit counters and indices)
   if (!n) return ANEMOI_OK;
   PermConsts pc;
   if ((rc = get_consts(field, width, &pc))) return rc;

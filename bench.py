@@ -31,8 +31,10 @@ Also printed in the same JSON line:
                 `traffic` comes from the committed rocprofv3 --pmc passes of this command and is
                 reported only when that profile was taken from the kernel sources being run
                 (csrc hash match); otherwise it is null and `traffic_stale` is true.
-  alu           v_mad_u64_u32 lane-operations per second / (1024 SIMDs x 16 lanes x clock), and -- so that a slow BOX and a slow
-                BUILD can be told apart from the line alone -- the same quantity for a fixed probe kernel run right after the
+  alu           v_mad_u64_u32 lane-operations per second / (1024 SIMDs x 16 lanes x clock) -- at the chip's 2.4 GHz maximum
+                (`frac`) and at the clock MEASURED during the timed steps by a sampler that sits beside the kernel
+                (`clock_GHz_measured*`, `frac_at_measured_clock`, `kernel_Mcycles_slowest_xcd`: what separates a slow BOX from a
+                slow BUILD in the line itself) -- and the same quantity for a fixed probe kernel run right after the
                 timed steps (anemoi_probe_issue_rate: a full grid, three wavefronts per SIMD, of dependent v_mad_u64_u32 chains):
                 `probe_lane_mad_per_s`, the clock the chip held during it (`probe_clock_GHz`, s_memtime / s_memrealtime), and the
                 same for a chain of the generated squaring, whose instruction mix is the kernel's (`probe_sqr_*`);
@@ -234,13 +236,21 @@ def main():
     d_out.zero_()                          # the check below must see what the TIMED steps wrote
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # the clock the chip holds DURING the timed steps: 16 single-wavefront sampler workgroups on a stream of their own, asleep
+    # between samples (anemoi_clock_sampler_*); started and stamped before the clock starts, stopped by the device itself
+    # behind the last step
+    sampler = A.ClockSampler(dev)
+    sampler.start(stream)
+    torch.cuda.current_stream().synchronize()
     t0 = time.perf_counter()
     for a, b in evs:
         a.record(stream)
         step()
         b.record(stream)
+    sampler.finish(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    clk_mean, clk_min, clk_max, clk_groups = sampler.read()
     if dist is not None:
         dist.barrier()
     elapsed = max_over_ranks(elapsed, dist, dev if backend == "nccl" else None)
@@ -323,6 +333,18 @@ def main():
                     # can overstate; at the maximum clock it cannot, on any box of the pool.
                     "peak_lane_mad_per_s": peak_lane_ops, "clock_GHz": MAX_GHZ, "clock_source": "maximum engine clock",
                     "frac": lane_mad_per_s / peak_lane_ops,
+                    # MEASURED in this run: the shader clock the chip held during the timed steps (mean / slowest / fastest of
+                    # 16 sampler workgroups spread over the XCDs; s_memtime against the 100 MHz s_memrealtime).  The boxes of
+                    # the pool differ in exactly this, by up to 3 %.  `frac_at_measured_clock` = the same multiply-add rate
+                    # against 1024 SIMDs x 16 lanes x the MEAN measured clock; `kernel_Mcycles_slowest_xcd` = kernel time x the
+                    # SLOWEST XCD's clock -- workgroups are dealt round-robin to the XCDs, the slowest one finishes last --
+                    # which is the box-independent cost of the build (226.7-228.3 on four boxes whose `value` differed by
+                    # 3 %; `frac_at_measured_clock` 0.748-0.755 there): a slower box moves `clock_GHz_measured*`, a slower
+                    # build moves `kernel_Mcycles_slowest_xcd` and `frac_at_measured_clock`.
+                    "clock_GHz_measured": clk_mean, "clock_GHz_measured_slowest_xcd": clk_min, "clock_GHz_measured_fastest_xcd": clk_max,
+                    "clock_sampler_groups": clk_groups,
+                    "frac_at_measured_clock": (lane_mad_per_s / (SIMDS * LANES_PER_CLK * clk_mean * 1e9)) if clk_mean else None,
+                    "kernel_Mcycles_slowest_xcd": (kernel_ms * clk_min) if clk_min else None,
                     # box or build?  Two fixed probe kernels on THIS GPU, right after the timed steps: bare dependent
                     # multiply-add chains (`probe_*`: what the instruction can do here, and the clock the chip holds for it)
                     # and a chain of the generated BLS12-381 squaring (`probe_sqr_*`: the instruction MIX and power draw of the

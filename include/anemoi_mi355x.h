@@ -120,6 +120,25 @@ int anemoi_warmup(int device, int field, int width);
 int anemoi_probe_issue_rate(int device, double *lane_mad_per_s, double *shader_clock_ghz, double *sqr_lane_mad_per_s,
                             double *sqr_shader_clock_ghz);
 
+/* The shader clock the chip HOLDS WHILE the caller's own kernels run -- what differs from box to box under this load, and
+ * what a process cannot otherwise read.  A sampler of 16 single-wavefront workgroups (one wave slot and a handful of
+ * registers each, asleep between samples, spread over the XCDs) is started on a stream of its own and logs (wall clock,
+ * shader-cycle counter) every period_us; the caller brackets its work with two wall-clock stamps on ITS stream, stops the
+ * sampler and reads the mean / min / max clock (GHz, over the sampler's workgroups) between the stamps:
+ *     buf = device memory of anemoi_clock_sampler_bytes(), 8-byte aligned; stamps = two device uint64
+ *     anemoi_clock_sampler_start_dev(buf, bytes, 2000, 60000, side_stream);   anemoi_clock_stamp_dev(&stamps[0], work_stream);
+ *     ... the work, on work_stream ...                                         anemoi_clock_stamp_dev(&stamps[1], work_stream);
+ *     anemoi_clock_sampler_stop_dev(buf, third_stream);   synchronise;   copy buf and stamps to the host;
+ *     anemoi_clock_sampler_read(host_buf, bytes, stamps[0], stamps[1], &mean, &lo, &hi, &groups);
+ * The sampler ends when stopped, when its log (4 096 samples) is full, or after max_ms, whichever comes first.  The stop
+ * must be issued on a stream that does not wait for the sampler.  bench.py reports the clock of its timed steps this way. */
+size_t anemoi_clock_sampler_bytes(void);
+int anemoi_clock_sampler_start_dev(void *d_buf, size_t bytes, unsigned period_us, unsigned max_ms, void *stream);
+int anemoi_clock_sampler_stop_dev(void *d_buf, void *stream);
+int anemoi_clock_stamp_dev(void *d_u64, void *stream);
+int anemoi_clock_sampler_read(const void *h_buf, size_t bytes, unsigned long long t0, unsigned long long t1, double *ghz_mean,
+                              double *ghz_min, double *ghz_max, int *groups_used);
+
 /* ---- options --------------------------------------------------------------------------------
  * anemoi_set_option(name, value): value -1 = automatic (the default).  `name` is the option name or its environment
  * variable.  Each option starts from its environment variable, read and validated ONCE at first use (a value that is
@@ -284,7 +303,7 @@ int anemoi_hash_bytes_ragged_dev(int field, int width, const void *d_msgs, const
 /* The same on an UNSORTED device-resident batch: the library first orders the messages by descending block count on the
  * device (a counting sort: histogram, scan, placement -- three small launches on `stream`), runs the ragged kernels in
  * that order and writes every digest to its message's own index.  d_scratch: anemoi_ragged_scratch_bytes(n) bytes of
- * device memory the caller owns (65 536 counters + n 32-bit indices), contents undefined afterwards; n < 2^32.  Only
+ * device memory the caller owns (65 536 counters + n 32-bit indices; 4-byte aligned), contents undefined afterwards; n < 2^32.  Only
  * launches and one memset on `stream`: capturable like the other `_dev` functions. */
 size_t anemoi_ragged_scratch_bytes(size_t n);
 int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void *d_msgs, const void *d_offsets, size_t n, void *d_out,

@@ -407,7 +407,31 @@ def test_warmup_and_issue_rate_probe(A, oracle):
     rate, ghz, sqr_rate, sqr_ghz = A.probe_issue_rate(0)
     assert 1.3e13 < sqr_rate < rate < 3.94e13, (rate, sqr_rate)
     assert 1.2 < ghz < 2.6 and 1.2 < sqr_ghz < 2.6, (ghz, sqr_ghz)
+    # the clock WHILE work runs: a sampler beside a Jive batch, bracketed by two stamps on the work's stream
     import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    work = torch.cuda.current_stream()
+    big = np.random.default_rng(6).integers(0, 1 << 60, size=(1 << 17, 2, 4), dtype=np.uint64)
+    d_in = torch.from_numpy(big.view(np.int64).reshape(-1)).to(dev)
+    d_out = torch.zeros((1 << 17) * 4, dtype=torch.int64, device=dev)
+    cs = A.ClockSampler(dev, period_us=500, max_ms=20000)
+    cs.start(work)
+    for _ in range(6):
+        assert A.lib.anemoi_jive_compress_k_dev(4, 2, 2, d_in.data_ptr(), d_out.data_ptr(), 1 << 17, work.cuda_stream) == 0
+    cs.finish(work)
+    t0 = time.perf_counter()
+    torch.cuda.synchronize()                       # returns as soon as the work is done: the device stops the sampler itself
+    assert time.perf_counter() - t0 < 5.0
+    mean, lo, hi, groups = cs.read()
+    assert groups == 16 and 1.2 < lo <= mean <= hi < 2.6, (mean, lo, hi, groups)
+    want = oracle.compress_batch(4, 2, big[:64], threads=2).reshape(64, 4)
+    assert (d_out.cpu().numpy().view(np.uint64).reshape(-1, 4)[:64] == want).all()      # the sampler changes no result
+    nb = A.lib.anemoi_clock_sampler_bytes()
+    assert A.lib.anemoi_clock_sampler_start_dev(None, nb, 1000, 1000, None) == -3
+    assert A.lib.anemoi_clock_sampler_start_dev(cs.buf.data_ptr(), nb - 1, 1000, 1000, None) == -3
+    assert A.lib.anemoi_clock_sampler_start_dev(cs.buf.data_ptr(), nb, 1, 1000, None) == -3      # period below 10 us
+    assert A.lib.anemoi_clock_stamp_dev(None, None) == -3 and A.lib.anemoi_clock_sampler_stop_dev(None, None) == -3
     assert A.lib.anemoi_probe_issue_rate(0, None, None, None, None) == -3
     v = [ctypes.c_double(0) for _ in range(4)]
     assert A.lib.anemoi_probe_issue_rate(99, *[ctypes.byref(x) for x in v]) == -4

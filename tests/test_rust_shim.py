@@ -59,6 +59,8 @@ def type_table():
         "long long": (C.c_longlong, "c_longlong"),
         "long long *": (P(C.c_longlong), "*mut c_longlong"),
         "double *": (P(C.c_double), "*mut c_double"),
+        "unsigned long long": (C.c_ulonglong, "c_ulonglong"),
+        "int *": (P(C.c_int), "*mut c_int"),
         "uint64_t *": (P(C.c_uint64), "*mut u64"),
         "const uint64_t *": (P(C.c_uint64), "*const u64"),
         "uint8_t *": (P(C.c_uint8), "*mut u8"),
