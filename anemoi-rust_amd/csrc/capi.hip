@@ -574,9 +574,12 @@ __global__ __launch_bounds__(64) void k_clock_sampler(SamplerBuf* buf, uint32_t 
   const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
   uint64_t next = t_begin;
   uint32_t n = 0;
-  for (;;) {
+  for (uint32_t it = 0;; it++) {
     const uint64_t t = __builtin_amdgcn_s_memrealtime();
-    const bool last = __hip_atomic_load(&buf->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || t - t_begin > max_ticks;
+    // the stop flag is read past the caches, so only every 16th turn (~45 us): polled on every turn, sixteen workgroups
+    // fetch ~35 MB per 100 ms -- a quarter of the headline kernel's own traffic, and it lands in that kernel's FETCH_SIZE
+    bool last = t - t_begin > max_ticks;
+    if ((it & 15u) == 0) last = last || __hip_atomic_load(&buf->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
     if (t >= next || last) {
       g.rec[n][0] = __builtin_amdgcn_s_memrealtime();
       g.rec[n][1] = __builtin_amdgcn_s_memtime();

@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=None,
                     help="items per GPU (default: 20 for N = 1 = config 2, 21 for N > 1 = config 4's shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-sampler", action="store_true",
+                    help="do not sample the shader clock beside the timed steps (the counter passes of tools/collect_profiles.sh: "
+                         "rocprofv3 --pmc serialises kernels, and the sampler's few reads would count as the kernel's traffic)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -239,18 +242,20 @@ def main():
     # the clock the chip holds DURING the timed steps: 16 single-wavefront sampler workgroups on a stream of their own, asleep
     # between samples (anemoi_clock_sampler_*); started and stamped before the clock starts, stopped by the device itself
     # behind the last step
-    sampler = A.ClockSampler(dev)
-    sampler.start(stream)
+    sampler = None if args.no_clock_sampler else A.ClockSampler(dev)
+    if sampler:
+        sampler.start(stream)
     torch.cuda.current_stream().synchronize()
     t0 = time.perf_counter()
     for a, b in evs:
         a.record(stream)
         step()
         b.record(stream)
-    sampler.finish(stream)
+    if sampler:
+        sampler.finish(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    clk_mean, clk_min, clk_max, clk_groups = sampler.read()
+    clk_mean, clk_min, clk_max, clk_groups = sampler.read() if sampler else (0.0, 0.0, 0.0, 0)
     if dist is not None:
         dist.barrier()
     elapsed = max_over_ranks(elapsed, dist, dev if backend == "nccl" else None)
@@ -338,9 +343,9 @@ def main():
                     # the pool differ in exactly this, by up to 3 %.  `frac_at_measured_clock` = the same multiply-add rate
                     # against 1024 SIMDs x 16 lanes x the MEAN measured clock; `kernel_Mcycles_slowest_xcd` = kernel time x the
                     # SLOWEST XCD's clock -- workgroups are dealt round-robin to the XCDs, the slowest one finishes last --
-                    # which is the box-independent cost of the build (226.7-228.3 on four boxes whose `value` differed by
-                    # 3 %; `frac_at_measured_clock` 0.748-0.755 there): a slower box moves `clock_GHz_measured*`, a slower
-                    # build moves `kernel_Mcycles_slowest_xcd` and `frac_at_measured_clock`.
+                    # which is the box-independent cost of the build (226.7-231.2 on boxes whose `value` ranged 9.30-10.79
+                    # M/s: profiles/r05/): a slower box moves `clock_GHz_measured*`, a slower build moves
+                    # `kernel_Mcycles_slowest_xcd` and `frac_at_measured_clock`.
                     "clock_GHz_measured": clk_mean, "clock_GHz_measured_slowest_xcd": clk_min, "clock_GHz_measured_fastest_xcd": clk_max,
                     "clock_sampler_groups": clk_groups,
                     "frac_at_measured_clock": (lane_mad_per_s / (SIMDS * LANES_PER_CLK * clk_mean * 1e9)) if clk_mean else None,

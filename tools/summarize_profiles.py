@@ -37,7 +37,10 @@ def rows(path):
 
 
 def counters(d):
-    """average per dispatch of the headline kernel, summed over a counter's hardware instances"""
+    """per dispatch of the headline kernel, summed over a counter's hardware instances: the MEDIAN over the dispatches of
+    the pass (rocprofv3 serialises the kernels of ONE queue; the counters of the last k_jive dispatch can take in the first
+    waves of a kernel that another queue starts right behind it -- bench.py's probes run on the library's own stream --
+    e.g. SQ_WAVES 19 456 = 16 384 + 3 072 in one dispatch of round 5's collection)"""
     path = find(d, "*counter_collection.csv")
     per = {}
     for r in rows(path):
@@ -48,7 +51,7 @@ def counters(d):
     out = {}
     for (name, _), v in per.items():
         out.setdefault(name, []).append(v)
-    return {k: sum(v) / len(v) for k, v in out.items()}
+    return {k: sorted(v)[len(v) // 2] for k, v in out.items()}
 
 
 def mad_counts():
@@ -127,7 +130,7 @@ def main():
         "counters_avg_per_launch": c, "derived": derived, "limb_layout": mc,
         "rocprofv3_stats_avg_ms": sum(dur) / len(dur), "rocprofv3_stats_calls": len(dur),
         "note": "rocprofv3 --pmc passes (separate runs for FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set) of `python3 "
-                "bench.py --steps 2 --warmup 1 --no-cpu-baseline` (tools/collect_profiles.sh); values are averages over "
+                "bench.py --steps 2 --warmup 1 --no-cpu-baseline` (tools/collect_profiles.sh); values are medians over "
                 "the k_jive dispatches, summed over a counter's hardware instances. FETCH_SIZE/WRITE_SIZE are in KiB; "
                 "FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read). "
                 "GRBM_GUI_ACTIVE is summed over the 8 XCDs. SQ_WAVE_CYCLES / SQ_ACTIVE_INST_VALU are quad-cycles. mad_* "
