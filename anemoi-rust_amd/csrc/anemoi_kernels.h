@@ -235,6 +235,19 @@ ANEMOI_KERNEL void k_jive_queue(const uint4* __restrict__ in, uint4* __restrict_
     __syncthreads();   // the staging area is reused by the next block
   }
 }
+// EXPERIMENT: one block per workgroup as in k_jive, but WHICH block is a ticket drawn from a counter, and the grid holds
+// more workgroups than there are blocks: the hardware still deals the workgroups to the XCDs round-robin, a faster XCD
+// gets through its share sooner and so draws more tickets, the surplus workgroups of the slower ones find none and leave.
+template <int FIELD, int W, int K>
+ANEMOI_KERNEL void k_jive_ticket(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n, PermConsts pc,
+                                 uint32_t* __restrict__ counter) {
+  extern __shared__ uint4 lds[];
+  uint32_t b = 0;
+  if (threadIdx.x == 0) b = atomicAdd(counter, 1u);
+  b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+  if (b >= uint32_t((n + kBlock - 1) / kBlock)) return;
+  jive_block<FIELD, W, K>(in, out, n, pc, b, lds);
+}
 #endif  // ANEMOI_AB_BUILD
 
 // One chunk of a byte message -> internal Montgomery element (from_le_bytes_mod_order + the
@@ -1019,7 +1032,10 @@ struct Launch {
 
 #if ANEMOI_AB_BUILD
   static hipError_t jive_queue(const void* in, void* out, size_t n, PermConsts pc, uint32_t* queue, unsigned wgs, hipStream_t s) {
-    k_jive_queue<FIELD, 2, 2><<<wgs, kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc, queue);
+    if (wgs >= grid_for(n))   // at least one workgroup per block: the ticket form (one block per workgroup, surplus workgroups leave)
+      k_jive_ticket<FIELD, 2, 2><<<wgs, kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc, queue);
+    else
+      k_jive_queue<FIELD, 2, 2><<<wgs, kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc, queue);
     return hipGetLastError();
   }
 #endif

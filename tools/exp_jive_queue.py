@@ -23,10 +23,15 @@ for lg in (20, 21):
     def static():
         assert A.lib.anemoi_jive_compress_k_dev(0, 2, 2, d_in.data_ptr(), d_a.data_ptr(), n, work.cuda_stream) == 0
     variants = [("static", static)]
-    for wgs in (3072, 2560, 6144):
+    for wgs in (3072, 6144):
         def queue(wgs=wgs):
             assert A.lib.anemoi_x_jive_queue_dev(0, d_in.data_ptr(), d_b.data_ptr(), n, q.data_ptr(), wgs, work.cuda_stream) == 0
         variants.append(("queue, %d workgroups" % wgs, queue))
+    for over in (1.0, 1.0625, 1.125, 1.25):     # tickets: one block per workgroup, `over` x as many workgroups as blocks
+        wgs = int(n // 64 * over)
+        def ticket(wgs=wgs):
+            assert A.lib.anemoi_x_jive_queue_dev(0, d_in.data_ptr(), d_b.data_ptr(), n, q.data_ptr(), wgs, work.cuda_stream) == 0
+        variants.append(("tickets, x %.4f" % over, ticket))
     for name, fn in variants:
         fn()
     torch.cuda.synchronize()

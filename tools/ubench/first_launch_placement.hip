@@ -93,6 +93,18 @@ static void launch(int grid, int iters, const char* label, Rec* d, uint32_t* o) 
   printf(" | in-kernel clock GHz min %.3f median %.3f max %.3f | wavefront us min %.0f median %.0f max %.0f | latest start +%.1f us | span %.3f ms\n",
          clk.front(), clk[clk.size() / 2], clk.back(), dur.front(), dur[dur.size() / 2], dur.back(), late,
          double(last - first) / 1e5);
+  // per XCD: when its last workgroup ended (ms after the first start of the launch) and the median clock of its workgroups
+  // -- are workgroups dealt to the XCDs statically (equal counts, the slow XCD ends last) or taken as slots free up?
+  printf("               per XCD last end ms / median GHz:");
+  for (int x = 0; x < 8; x++) {
+    uint64_t e = 0;
+    std::vector<double> c;
+    for (auto& r : h)
+      if (int(r.xcc_id & 7) == x) e = std::max(e, r.t1), c.push_back(double(r.c1 - r.c0) / double(r.t1 - r.t0) * 0.1);
+    std::sort(c.begin(), c.end());
+    printf(" %.2f/%.3f", c.empty() ? 0.0 : double(e - first) / 1e5, c.empty() ? 0.0 : c[c.size() / 2]);
+  }
+  printf("\n");
   fflush(stdout);
 }
 
