@@ -759,7 +759,10 @@ int anemoi_probe_issue_rate(int device, double* lane_mad_per_s, double* shader_c
     auto run = [&](bool squarings, int iters, int mads_per_iter, double* rate, double* clock) -> int {
       hipEvent_t a = nullptr, b = nullptr;
       HIP_TRY(hipEventCreate(&a));
-      HIP_TRY(hipEventCreate(&b));
+      if (hipError_t eb = hipEventCreate(&b); eb != hipSuccess) {
+        (void)hipEventDestroy(a);
+        HIP_TRY(eb);
+      }
       if (squarings) k_issue_probe_sqr<<<grid, 64, 0, ln.s_k>>>(rec, iters / 4);
       else k_issue_probe<<<grid, 64, 0, ln.s_k>>>(rec, iters / 8);
       (void)hipEventRecord(a, ln.s_k);
@@ -779,7 +782,7 @@ int anemoi_probe_issue_rate(int device, double* lane_mad_per_s, double* shader_c
         if (h[3 * i]) ghz.push_back(double(h[3 * i + 1]) / double(h[3 * i]) * 0.1);   // cycles per 10 ns tick
       std::sort(ghz.begin(), ghz.end());
       *clock = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
-      *rate = double(grid) * 64.0 * double(iters) * double(mads_per_iter) / (double(ms) * 1e-3);
+      *rate = ms > 0 ? double(grid) * 64.0 * double(iters) * double(mads_per_iter) / (double(ms) * 1e-3) : 0.0;
       return ANEMOI_OK;
     };
     if ((r = run(false, 60000, kProbeMadsPerIter, lane_mad_per_s, shader_clock_ghz))) return r;   // ~20 ms
@@ -792,7 +795,9 @@ int anemoi_probe_issue_rate(int device, double* lane_mad_per_s, double* shader_c
 size_t anemoi_clock_sampler_bytes(void) { return sizeof(SamplerBuf); }
 
 int anemoi_clock_sampler_start_dev(void* d_buf, size_t bytes, unsigned period_us, unsigned max_ms, void* stream) {
-  if (!d_buf || bytes < sizeof(SamplerBuf) || (uintptr_t)d_buf % 8 || period_us < 10 || max_ms < 1 || max_ms > 600000) return ANEMOI_ERR_ARG;
+  if (!d_buf || bytes < sizeof(SamplerBuf) || (uintptr_t)d_buf % 8 || period_us < 10 || period_us > 1000000 ||
+      max_ms < 1 || max_ms > 600000)
+    return ANEMOI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(d_buf, 0, offsetof(SamplerBuf, g), s));                    // stop = 0
   for (int i = 0; i < kSamplerGroups; i++)                                            // count = 0 of every group

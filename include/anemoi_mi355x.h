@@ -130,6 +130,7 @@ int anemoi_probe_issue_rate(int device, double *lane_mad_per_s, double *shader_c
  *     ... the work, on work_stream ...                                         anemoi_clock_stamp_dev(&stamps[1], work_stream);
  *     anemoi_clock_sampler_stop_dev(buf, third_stream);   synchronise;   copy buf and stamps to the host;
  *     anemoi_clock_sampler_read(host_buf, bytes, stamps[0], stamps[1], &mean, &lo, &hi, &groups);
+ * (period_us 10 ... 1 000 000, max_ms 1 ... 600 000, else ANEMOI_ERR_ARG.)
  * The sampler ends when stopped, when its log (4 096 samples) is full, or after max_ms, whichever comes first.  The stop
  * must be issued on a stream that does not wait for the sampler.  bench.py reports the clock of its timed steps this way. */
 size_t anemoi_clock_sampler_bytes(void);
