@@ -23,4 +23,4 @@ def test_fuzz_all_kernel_families_against_the_oracle(oracle):
     took = time.time() - t0
     assert not failed, "\n".join(log)
     assert len(log) == 14 + 14 + 6, log           # every (field, width) line of every section was produced
-    assert took < 60, "the in-suite fuzz is meant to stay short (%.1f s)" % took
+    assert took < 240, "the in-suite fuzz is meant to stay short (%.1f s; ~15 s on a 16-core box share)" % took
