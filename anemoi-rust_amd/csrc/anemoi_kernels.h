@@ -932,6 +932,26 @@ struct Launch {
   static hipError_t sponge_ragged(int width, const void* msgs, const void* off, size_t n, void* out, PermConsts pc,
                                   const void* order, hipStream_t s) {
     if (!n) return hipSuccess;
+    // small batches: the latency kernels, at the cut-offs of the equal-length sponge (sponge_seg above)
+    const uint8_t* m = (const uint8_t*)msgs;
+    const uint64_t* o = (const uint64_t*)off;
+    const uint32_t* ord = (const uint32_t*)order;
+    if (width == 2 && n <= coop2d_max_items(pc.simds)) {  // two messages per wavefront
+      const size_t groups = (n + 1) / 2;
+      k_sponge_ragged_coop<FIELD, 2, 32><<<unsigned(groups < 65536 ? groups : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      return hipGetLastError();
+    }
+    if (width == 4 && n <= coop2d43_max_items(pc.simds)) {  // one 4-3 message per wavefront
+      k_sponge_ragged_coop<FIELD, 4, 32><<<unsigned(n < 65536 ? n : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      return hipGetLastError();
+    }
+    if (n <= coop_sponge_max_items(pc.simds)) {  // four (2-1) / two (4-3) messages per wavefront on the scan
+      const size_t groups = width == 2 ? (n + 3) / 4 : (n + 1) / 2;
+      const unsigned g = unsigned(groups < 65536 ? groups : 65536);
+      if (width == 2) k_sponge_ragged_coop<FIELD, 2, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      else k_sponge_ragged_coop<FIELD, 4, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      return hipGetLastError();
+    }
     if (width == 2)
       k_sponge_ragged<FIELD><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>((const uint8_t*)msgs, (const uint64_t*)off,
                                                                                 n, (uint4*)out, pc, (const uint32_t*)order);

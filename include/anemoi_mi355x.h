@@ -298,7 +298,9 @@ int anemoi_hash_bytes_dev(int field, int width, const void *d_msgs, size_t msg_l
                           void *stream);
 /* d_offsets: n + 1 uint64 byte offsets into d_msgs (see anemoi_hash_bytes_ragged_batch).  Messages are processed IN THE
  * GIVEN ORDER, 64 (Anemoi-2-1) or 32 (4-3) consecutive messages per wavefront, and a wavefront runs as long as its longest
- * message: right for batches that are already grouped by length; for anything else use the bucketed form below. */
+ * message: right for batches that are already grouped by length; for anything else use the bucketed form below.  Small
+ * batches (up to the cut-offs of the equal-length sponge: options coop2d_max / coop2d43_max / coop_sponge_max) take the
+ * latency kernels like an equal-length batch does -- 2 or 4 (Anemoi-2-1) / 1 or 2 (4-3) messages per wavefront. */
 int anemoi_hash_bytes_ragged_dev(int field, int width, const void *d_msgs, const void *d_offsets, size_t n, void *d_out,
                                  void *stream);
 /* The same on an UNSORTED device-resident batch: the library first orders the messages by descending block count on the

@@ -641,12 +641,14 @@ struct Walk {
   }
   // a cooperative kernel: one emulated lane per column (W = 2: lane 0; W = 4: lanes 0 and LPI)
   template <int LPI>
-  void coop_case(const std::string& name, const std::function<void(const PermConsts&)>& body) {
+  void coop_case(const std::string& name, const std::function<void(const PermConsts&)>& body, std::vector<int> ids = {}) {
     walk::begin_case(name, FIELD, LPI == 32 ? "fold" : "scan");
     coop_tables();
     const PermConsts p = pc;
-    std::vector<int> ids{0};
-    if (width == 4) ids.push_back(LPI);
+    if (ids.empty()) {   // one item: its column(s)
+      ids.push_back(0);
+      if (width == 4) ids.push_back(LPI);
+    }
     walk::run_lanes(ids, [&] { body(p); });
   }
 
@@ -783,6 +785,12 @@ struct Walk {
           k_sponge_coop<FIELD, 2, false, LPI>(in.data(), 2, 1, out.data(), pc, tail);
         });
       }
+      {   // ragged: two messages in one wavefront (lane 0 and lane LPI: the next row / row pair), one ends two blocks early
+        const std::vector<uint64_t> off{0, 3 * ch + 5, 4 * ch + 7};
+        w.template coop_case<LPI>("k_sponge_ragged_coop<2," + t, [&](const PermConsts& pc) {
+          k_sponge_ragged_coop<FIELD, 2, LPI>(bytes.data(), off.data(), 2, out.data(), pc, nullptr);
+        }, {0, LPI});
+      }
     }
     {
       Walk w(4);
@@ -811,6 +819,17 @@ struct Walk {
         w.template coop_case<LPI>("k_sponge_coop<4,elements," + t + " last segment", [&](const PermConsts& pc) {
           k_sponge_coop<FIELD, 4, false, LPI>(in.data(), 4, 1, out.data(), pc, tail);
         });
+      }
+      {   // ragged 4-3: 8 elements (padded to 9) beside 2 (padded to 3); the scan holds both states in one wavefront, the fold one
+        const std::vector<uint64_t> off{0, 7 * ch + 5, 9 * ch + 5};
+        const std::vector<int> lanes = LPI == 16 ? std::vector<int>{0, 16, 32, 48} : std::vector<int>{0, 32};
+        w.template coop_case<LPI>("k_sponge_ragged_coop<4," + t, [&](const PermConsts& pc) {
+          k_sponge_ragged_coop<FIELD, 4, LPI>(bytes.data(), off.data(), LPI == 16 ? 2 : 1, out.data(), pc, nullptr);
+        }, lanes);
+        if (LPI == 32)   // ... and the short message alone on the fold kernel
+          w.template coop_case<LPI>("k_sponge_ragged_coop<4," + t + " short message", [&](const PermConsts& pc) {
+            k_sponge_ragged_coop<FIELD, 4, LPI>(bytes.data(), off.data() + 1, 1, out.data(), pc, nullptr);
+          }, lanes);
       }
     }
   }

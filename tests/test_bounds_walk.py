@@ -60,11 +60,13 @@ COOP_FAMILIES = ["k_jive2_coop<%s>", "k_permutation_coop<2,%s>", "k_merkle_climb
 for _w in (2, 4):
     COOP_FAMILIES += ["k_sponge_coop<%d,bytes,%%s> %s" % (_w, part) for part in ("whole", "first segment", "last segment")]
     COOP_FAMILIES += ["k_sponge_coop<%d,elements,%%s> %s" % (_w, part) for part in ("whole", "last segment")]
+    COOP_FAMILIES += ["k_sponge_ragged_coop<%d,%%s>" % _w]     # two messages of different lengths in one wavefront
 
 
 def test_the_walk_covers_every_kernel_family(logs):
     want = ["lane " + c for c in LANE_FAMILIES] + ["lane run-time instance, NUM_COLUMNS = %d" % c for c in range(1, 17)]
     want += ["scan " + c % "16" for c in COOP_FAMILIES] + ["fold " + c % "32" for c in COOP_FAMILIES]
+    want += ["fold k_sponge_ragged_coop<4,32> short message"]   # (the 4-3 fold kernel holds one message per wavefront)
     for f, log in logs.items():
         assert sorted(log.cases) == sorted(want), FIELD_IDS[f]
         # ... and every arithmetic statement of the headers was reached on every field's walk where it exists

@@ -310,6 +310,52 @@ def test_ragged_batch_of_messages_of_different_lengths(A, oracle):
                                                 out.ctypes.data_as(_lib._u64p), 0) == -3
 
 
+def test_small_ragged_batches_on_every_kernel_family(A, oracle):
+    """Round 5: a SMALL ragged batch takes the latency kernels (k_sponge_ragged_coop: two-row fold up to one wavefront per
+    SIMD, the scan up to four) like an equal-length one; the lane-private ragged kernels beyond.  Every field, both widths,
+    each of the three routings forced through the cut-off options, batch sizes that leave rows of the last wavefront
+    idle, lengths 0 / 1 / around the chunk and the rate block / long next to short in one wavefront (a message that has
+    ended keeps its state while its neighbour runs on) -- host entry point (bucketed inside the library) and the
+    device-side bucketed one (an `order` array in front of the same kernels); every digest = the oracle's hash of that
+    message alone."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(515)
+    routes = {"fold": {}, "scan": dict(coop2d_max=0, coop2d43_max=0),
+              "lane-private": dict(coop2d_max=0, coop2d43_max=0, coop_sponge_max=0)}
+    for fid, field in enumerate(FIELD_IDS):
+        for width in (2, 4):
+            inst = A.Anemoi(field, width)
+            c, r, L = inst.chunk, width - 1, inst.limbs
+            lens = [7 * c + 3, 0, 1, c - 1, c, c + 1, r * c - 1, r * c, r * c + 1, 2 * r * c, 2 * r * c + c, 0, 5, 11 * c]
+            lens += [int(v) for v in rng.integers(0, 6 * c, size=9)]                 # 23 messages: odd, not a multiple of 4
+            msgs = [rng.integers(0, 256, size=n, dtype=np.uint8).tobytes() for n in lens]
+            want = np.stack([oracle.hash_bytes(fid, width, m) for m in msgs])
+            n = len(msgs)
+            offs = np.zeros(n + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum(lens, dtype=np.uint64)
+            d_blob = torch.from_numpy(np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()).to(dev)
+            d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+            need = A.lib.anemoi_ragged_scratch_bytes(n)
+            d_scr = torch.empty(need, dtype=torch.uint8, device=dev)
+            for name, opts in routes.items():
+                with A.options(**opts):
+                    assert (inst.hash_ragged(msgs) == want).all(), (field, width, name, "host")
+                    assert (inst.hash_ragged(msgs[:1]) == want[:1]).all() and (inst.hash_ragged(msgs[:2]) == want[:2]).all()
+                    for bucketed in (0, 1):
+                        d_out = torch.zeros(n * L, dtype=torch.int64, device=dev)
+                        if bucketed:
+                            rc = A.lib.anemoi_hash_bytes_ragged_bucketed_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n,
+                                                                             d_out.data_ptr(), d_scr.data_ptr(), need, s)
+                        else:
+                            rc = A.lib.anemoi_hash_bytes_ragged_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n, d_out.data_ptr(), s)
+                        assert rc == 0
+                        torch.cuda.synchronize()
+                        got = d_out.cpu().numpy().view(np.uint64).reshape(n, L)
+                        assert (got == want).all(), (field, width, name, "bucketed" if bucketed else "in order")
+
+
 def test_unsorted_device_resident_ragged_batch_is_bucketed_on_the_device(A, oracle):
     """anemoi_hash_bytes_ragged_bucketed_dev: the device-side counting sort by block count in front of the ragged kernels
     (the device-resident counterpart of the host path's bucketing).  A long-tailed UNSORTED batch -- most messages short,

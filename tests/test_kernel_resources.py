@@ -25,7 +25,7 @@ def test_every_kernel_of_every_field_is_in_the_table(rows):
     names = {(r["kernel"].split("<")[0], r["field"]) for r in rows}
     for f in kr.FIELDS:
         for k in ("k_jive", "k_jive_pair", "k_sponge", "k_sponge_pair", "k_sponge_ragged", "k_sponge_ragged_pair",
-                  "k_permutation", "k_permutation_pair", "k_merkle_climb", "k_jive2_coop", "k_jive4_coop", "k_sponge_coop", "k_permutation_coop", "k_merkle_climb_coop", "k_mont_convert",
+                  "k_permutation", "k_permutation_pair", "k_merkle_climb", "k_jive2_coop", "k_jive4_coop", "k_sponge_coop", "k_sponge_ragged_coop", "k_permutation_coop", "k_merkle_climb_coop", "k_mont_convert",
                   "k_permutation_cols", "k_jive_cols", "k_sponge_cols", "k_exp_alpha"):
             assert (k, f) in names, (k, f)
 
