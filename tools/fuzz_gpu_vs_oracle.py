@@ -5,7 +5,7 @@
                 11-limb fields, the scan on the 15-limb ones)
   Jive 4-3      lane-pair, row-cooperative and two-row fold (one state per wavefront), k = 2 and 4
   permutation   the default routing of the batch size
-  sponge        two-row / row-cooperative / lane-private kernels on equal-length batches, the ragged kernel on all
+  sponge        two-row / row-cooperative / lane-private kernels on equal-length batches, the three ragged kernels on all
                 lengths in one batch, the segment-fed host path (tiny forced segments)
   generic       the run-time-instance kernels fed with the shipped constants (3 fields)
 
@@ -131,8 +131,13 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
                         ok = ok and (inst.hash_batch(msgs) == exp).all()
                 ragged += [m.tobytes() for m in msgs]
                 want.append(exp)
-            ok = ok and (inst.hash_ragged(ragged) == np.concatenate(want)).all()      # ragged kernel, all lengths in one batch
-            log("%-16s W=%d sponge, %d lengths x 5 messages (default, row-coop, lane-private, segments, ragged): %s"
+            # all lengths in one ragged batch: the two-row fold, the row-cooperative and the lane-private ragged kernels
+            ok = ok and (inst.hash_ragged(ragged) == np.concatenate(want)).all()
+            with A.options(coop2d_max=0, coop2d43_max=0):
+                ok = ok and (inst.hash_ragged(ragged) == np.concatenate(want)).all()
+            with A.options(**LANE):
+                ok = ok and (inst.hash_ragged(ragged) == np.concatenate(want)).all()
+            log("%-16s W=%d sponge, %d lengths x 5 messages (default, row-coop, lane-private, segments; ragged on the three): %s"
                 % (field, width, len(lens), check(ok, (field, width, "sponge"))))
     if generic:   # the run-time-instance kernels fed with the shipped constants reproduce the fixed instances
         for field in ("bn_254", "bls12_381", "ed_on_bls12_377"):
