@@ -85,9 +85,12 @@ _SIGS = {
     "anemoi_hash_field_batch": ([_int, _int, _u64p, _sz, _sz, _u64p, _int], _int),
     "anemoi_hash_bytes_batch": ([_int, _int, _u8p, _sz, _sz, _u64p, _int], _int),
     "anemoi_hash_bytes_ragged_batch": ([_int, _int, _u8p, _u64p, _sz, _u64p, _int], _int),
+    "anemoi_hash_field_ragged_batch": ([_int, _int, _u64p, _u64p, _sz, _u64p, _int], _int),
     "anemoi_hash_bytes_ragged_dev": ([_int, _int, _vp, _vp, _sz, _vp, _vp], _int),
     "anemoi_ragged_scratch_bytes": ([_sz], _sz),
     "anemoi_hash_bytes_ragged_bucketed_dev": ([_int, _int, _vp, _vp, _sz, _vp, _vp, _sz, _vp], _int),
+    "anemoi_hash_field_ragged_dev": ([_int, _int, _vp, _vp, _sz, _vp, _vp], _int),
+    "anemoi_hash_field_ragged_bucketed_dev": ([_int, _int, _vp, _vp, _sz, _vp, _vp, _sz, _vp], _int),
     "anemoi_merkle_root": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
     "anemoi_merkle_tree": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
     "anemoi_merkle_path": ([_int, _u64p, ctypes.c_uint, _sz, _u64p], _int),
@@ -405,6 +408,18 @@ class Anemoi:
         out = np.empty((len(lens), self.limbs), dtype=np.uint64)
         _check(lib.anemoi_hash_bytes_ragged_batch(self.field, self.width, _p8(blob) if blob.size else None, _p64(offs),
                                                   len(lens), _p64(out) if len(lens) else None, self.device))
+        return out
+
+    def hash_field_ragged(self, messages):
+        """Sponge::hash_field of each of `messages` (a sequence of arrays of elements, (k_i, limbs) each, any k_i >= 0) in
+        one launch."""
+        arrs = [np.ascontiguousarray(m, dtype=np.uint64).reshape(-1, self.limbs) for m in messages]
+        offs = np.zeros(len(arrs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(a) for a in arrs], dtype=np.uint64)
+        blob = np.concatenate(arrs) if arrs and int(offs[-1]) else np.zeros((0, self.limbs), dtype=np.uint64)
+        out = np.empty((len(arrs), self.limbs), dtype=np.uint64)
+        _check(lib.anemoi_hash_field_ragged_batch(self.field, self.width, _p64(blob) if blob.size else None, _p64(offs),
+                                                  len(arrs), _p64(out) if len(arrs) else None, self.device))
         return out
 
     def merkle_root(self, leaves, depth):

@@ -475,8 +475,9 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
 // has ended keeps its state (selects, no divergent control flow: the cooperative products run under a full EXEC mask
 // whatever the lengths are).  Every live message is at the same position of its rate block (pos = e mod RATE), so the
 // only permutation that is not shared is the one behind a message's LAST element: it runs for the whole wavefront and
-// the other messages, if in mid-block, drop its result.  `order` as in k_sponge_ragged (slot -> message).
-template <int FIELD, int W, int LPR = 16>
+// the other messages, if in mid-block, drop its result.  `order` and BYTES as in k_sponge_ragged (slot -> message; byte
+// messages with byte offsets, or messages of ABI elements with offsets in elements).
+template <int FIELD, int W, bool BYTES, int LPR = 16>
 __global__ __launch_bounds__(kBlock) void k_sponge_ragged_coop(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off,
                                                                size_t n, uint32_t* __restrict__ out, PermConsts pc,
                                                                const uint32_t* __restrict__ order) {
@@ -495,17 +496,22 @@ __global__ __launch_bounds__(kBlock) void k_sponge_ragged_coop(const uint8_t* __
     const size_t slot = live ? want : n - 1;
     const size_t item = order ? size_t(order[slot]) : slot;
     const uint64_t o0 = off[item], len = off[item + 1] - o0;
-    const uint8_t* msg = msgs + o0;
-    const size_t num = (len + F::kChunk - 1) / F::kChunk;
+    const uint8_t* msg = msgs + o0 * (BYTES ? 1 : NABI * 4);
+    const size_t num = BYTES ? (len + F::kChunk - 1) / F::kChunk : len;
     const unsigned tot = unsigned(num + (num % RATE == 0 ? 0 : 1));   // + the padding element 1 (never for RATE = 1)
     const unsigned steps = wave_max(tot);
     uint32_t x = 0, y = 0;   // this column's part of the state: x = state[col], y = state[W/2 + col]
 #pragma nounroll
     for (unsigned e = 0; e < steps; e++) {
       const bool active = e < tot, have = e < num;
-      const size_t c0 = have ? size_t(e) * F::kChunk : 0;
-      const int clen = !have ? 0 : len - c0 < uint64_t(F::kChunk) ? int(len - c0) : F::kChunk;   // (nothing is read when clen = 0)
-      uint32_t el = C::to_mont(coop_chunk_limb<F, C>(msg + c0, clen, j), k);
+      uint32_t el;
+      if (BYTES) {
+        const size_t c0 = have ? size_t(e) * F::kChunk : 0;
+        const int clen = !have ? 0 : len - c0 < uint64_t(F::kChunk) ? int(len - c0) : F::kChunk;   // (nothing is read when clen = 0)
+        el = C::to_mont(coop_chunk_limb<F, C>(msg + c0, clen, j), k);
+      } else {
+        el = C::from_abi(have && j < NABI ? ((const uint32_t*)msg)[size_t(e) * NABI + j] : 0u, k);
+      }
       el = have ? el : k.one;
       const int pos = int(e % RATE);   // wave-uniform: every message still running is at the same place of its block
       const uint32_t sx = C::add(x, el), sy = C::add(y, el);

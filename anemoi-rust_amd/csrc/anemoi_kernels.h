@@ -524,7 +524,8 @@ __device__ __forceinline__ void store_digest(uint4* __restrict__ dst, const type
 // `order` (may be null): slot j of the launch works on message order[j] and its digest goes to out[order[j]] -- the
 // device-side bucketing of anemoi_hash_bytes_ragged_bucketed_dev (k_ragged_hist / _scan / _place below): messages by
 // descending block count, so that the lanes of a wavefront run out of blocks together.
-template <int FIELD>
+// BYTES: messages of bytes, offsets in bytes (Sponge::hash); else messages of ABI elements, offsets in ELEMENTS (hash_field).
+template <int FIELD, bool BYTES>
 ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off, size_t n,
                                    uint4* __restrict__ out, PermConsts pc, const uint32_t* __restrict__ order) {
   using F = FieldC<FIELD>;
@@ -536,8 +537,8 @@ ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint6
   const size_t slot = blk0 + (threadIdx.x < cnt ? threadIdx.x : 0);  // idle lanes redo item blk0
   const size_t item = order ? size_t(order[slot]) : slot;
   const uint64_t o0 = off[item], len = off[item + 1] - o0;
-  const uint8_t* msg = msgs + o0;
-  const size_t num = (len + F::kChunk - 1) / F::kChunk;  // RATE = 1: no padding element ever
+  const uint8_t* msg = msgs + o0 * (BYTES ? 1 : A::NABI * 4);
+  const size_t num = BYTES ? (len + F::kChunk - 1) / F::kChunk : len;  // RATE = 1: no padding element ever
   const unsigned blocks = (unsigned)num, bmax = wave_max(blocks);
   typename A::Fe st[2], dig;
   A::set_zero(st[0]);
@@ -548,7 +549,7 @@ ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint6
   for (unsigned b = 0; b < bmax; b++) {
     if (b < blocks) {
       typename A::Fe el;
-      sponge_element<F, A, true>(el, msg, b, 0, num, len);
+      sponge_element<F, A, BYTES>(el, msg, b, 0, num, len);
       A::add(st[0], st[0], el);
     }
     permutation<F, A, 2, WIN>(st, pc, tab);
@@ -563,7 +564,7 @@ ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint6
   block_store<A::NABI / 4>(lds, out, blk0, cnt);
 }
 
-template <int FIELD>
+template <int FIELD, bool BYTES>
 ANEMOI_KERNEL void k_sponge_ragged_pair(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off, size_t n,
                                         uint4* __restrict__ out, PermConsts pc, const uint32_t* __restrict__ order) {
   using F = FieldC<FIELD>;
@@ -577,8 +578,8 @@ ANEMOI_KERNEL void k_sponge_ragged_pair(const uint8_t* __restrict__ msgs, const 
   const size_t slot = st0 + (s < cnt ? s : 0);  // idle lane pairs redo item st0
   const size_t item = order ? size_t(order[slot]) : slot;
   const uint64_t o0 = off[item], len = off[item + 1] - o0;
-  const uint8_t* msg = msgs + o0;
-  const size_t num = (len + F::kChunk - 1) / F::kChunk;
+  const uint8_t* msg = msgs + o0 * (BYTES ? 1 : A::NABI * 4);
+  const size_t num = BYTES ? (len + F::kChunk - 1) / F::kChunk : len;
   const size_t total = num + (num % RATE == 0 ? 0 : 1);  // + the padding element 1
   const unsigned blocks = (unsigned)((total + RATE - 1) / RATE), bmax = wave_max(blocks);
   typename A::Fe x, y, dig;
@@ -593,7 +594,7 @@ ANEMOI_KERNEL void k_sponge_ragged_pair(const uint8_t* __restrict__ msgs, const 
       const size_t e = size_t(b) * RATE + r;
       if (e < total) {
         typename A::Fe el, t;
-        sponge_element<F, A, true>(el, msg, e, 0, num, len);
+        sponge_element<F, A, BYTES>(el, msg, e, 0, num, len);
         if (r < 2) {
           A::add(t, x, el);
           fe_select<A>(x, odd == (r == 1), t, x);
@@ -718,8 +719,9 @@ struct FieldOps {
   hipError_t (*sponge_seg)(int width, int bytes, const void* d_src, size_t per_msg, size_t n, void* d_out, PermConsts pc,
                            SpongeSeg seg, hipStream_t s);
   // messages of different lengths: message i = bytes [off[i], off[i+1]) of d_msgs
+  // (bytes: byte messages and byte offsets; else messages of ABI elements and offsets in elements)
   // d_order: null, or n 32-bit message indices (slot j works on message d_order[j] and writes out[d_order[j]])
-  hipError_t (*sponge_ragged)(int width, const void* d_msgs, const void* d_off, size_t n, void* d_out, PermConsts pc,
+  hipError_t (*sponge_ragged)(int width, int bytes, const void* d_msgs, const void* d_off, size_t n, void* d_out, PermConsts pc,
                               const void* d_order, hipStream_t s);
   hipError_t (*mont_convert)(int to, const void* d_in, void* d_out, size_t count, hipStream_t s);
   hipError_t (*merkle_climb)(const void* d_leaves, const void* d_index, const void* d_paths, unsigned depth, size_t n,
@@ -929,35 +931,39 @@ struct Launch {
     return sponge_seg(width, bytes, src, per_msg, n, out, pc, SpongeSeg{nullptr, 0, per_msg, 1, 1}, s);
   }
 
-  static hipError_t sponge_ragged(int width, const void* msgs, const void* off, size_t n, void* out, PermConsts pc,
+  static hipError_t sponge_ragged(int width, int bytes, const void* msgs, const void* off, size_t n, void* out, PermConsts pc,
                                   const void* order, hipStream_t s) {
     if (!n) return hipSuccess;
+    return bytes ? sponge_ragged_as<true>(width, msgs, off, n, out, pc, order, s)
+                 : sponge_ragged_as<false>(width, msgs, off, n, out, pc, order, s);
+  }
+  template <bool BYTES>
+  static hipError_t sponge_ragged_as(int width, const void* msgs, const void* off, size_t n, void* out, PermConsts pc,
+                                     const void* order, hipStream_t s) {
     // small batches: the latency kernels, at the cut-offs of the equal-length sponge (sponge_seg above)
     const uint8_t* m = (const uint8_t*)msgs;
     const uint64_t* o = (const uint64_t*)off;
     const uint32_t* ord = (const uint32_t*)order;
     if (width == 2 && n <= coop2d_max_items(pc.simds)) {  // two messages per wavefront
       const size_t groups = (n + 1) / 2;
-      k_sponge_ragged_coop<FIELD, 2, 32><<<unsigned(groups < 65536 ? groups : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      k_sponge_ragged_coop<FIELD, 2, BYTES, 32><<<unsigned(groups < 65536 ? groups : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
       return hipGetLastError();
     }
     if (width == 4 && n <= coop2d43_max_items(pc.simds)) {  // one 4-3 message per wavefront
-      k_sponge_ragged_coop<FIELD, 4, 32><<<unsigned(n < 65536 ? n : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      k_sponge_ragged_coop<FIELD, 4, BYTES, 32><<<unsigned(n < 65536 ? n : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
       return hipGetLastError();
     }
     if (n <= coop_sponge_max_items(pc.simds)) {  // four (2-1) / two (4-3) messages per wavefront on the scan
       const size_t groups = width == 2 ? (n + 3) / 4 : (n + 1) / 2;
       const unsigned g = unsigned(groups < 65536 ? groups : 65536);
-      if (width == 2) k_sponge_ragged_coop<FIELD, 2, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
-      else k_sponge_ragged_coop<FIELD, 4, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      if (width == 2) k_sponge_ragged_coop<FIELD, 2, BYTES, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      else k_sponge_ragged_coop<FIELD, 4, BYTES, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
       return hipGetLastError();
     }
     if (width == 2)
-      k_sponge_ragged<FIELD><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>((const uint8_t*)msgs, (const uint64_t*)off,
-                                                                                n, (uint4*)out, pc, (const uint32_t*)order);
+      k_sponge_ragged<FIELD, BYTES><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>(m, o, n, (uint4*)out, pc, ord);
     else
-      k_sponge_ragged_pair<FIELD><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(
-          (const uint8_t*)msgs, (const uint64_t*)off, n, (uint4*)out, pc, (const uint32_t*)order);
+      k_sponge_ragged_pair<FIELD, BYTES><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(m, o, n, (uint4*)out, pc, ord);
     return hipGetLastError();
   }
 

@@ -467,13 +467,13 @@ __global__ void k_assemble4(const uint4* __restrict__ cur, const uint4* __restri
 // exclusive scan from the longest bucket down, placement by atomic cursor.  Not stable -- equal block counts land in
 // any order, which costs nothing -- and every digest goes back to its message's own index.
 constexpr int kRaggedBins = 1 << 16;
-__device__ __forceinline__ uint32_t ragged_bin(const uint64_t* __restrict__ off, size_t i, uint32_t block_bytes) {
-  const uint64_t blocks = (off[i + 1] - off[i] + block_bytes - 1) / block_bytes;
+__device__ __forceinline__ uint32_t ragged_bin(const uint64_t* __restrict__ off, size_t i, uint32_t block_units) {
+  const uint64_t blocks = (off[i + 1] - off[i] + block_units - 1) / block_units;
   return uint32_t(kRaggedBins - 1) - uint32_t(blocks < uint64_t(kRaggedBins - 1) ? blocks : uint64_t(kRaggedBins - 1));   // bin 0 = the longest
 }
-__global__ void k_ragged_hist(const uint64_t* __restrict__ off, size_t n, uint32_t block_bytes, uint32_t* __restrict__ bins) {
+__global__ void k_ragged_hist(const uint64_t* __restrict__ off, size_t n, uint32_t block_units, uint32_t* __restrict__ bins) {
   const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) atomicAdd(&bins[ragged_bin(off, i, block_bytes)], 1u);
+  if (i < n) atomicAdd(&bins[ragged_bin(off, i, block_units)], 1u);
 }
 // counts -> first slot of each bin (one workgroup of 1 024 threads, 64 bins each)
 __global__ __launch_bounds__(1024) void k_ragged_scan(uint32_t* __restrict__ bins) {
@@ -496,10 +496,10 @@ __global__ __launch_bounds__(1024) void k_ragged_scan(uint32_t* __restrict__ bin
     run += c;
   }
 }
-__global__ void k_ragged_place(const uint64_t* __restrict__ off, size_t n, uint32_t block_bytes, uint32_t* __restrict__ bins,
+__global__ void k_ragged_place(const uint64_t* __restrict__ off, size_t n, uint32_t block_units, uint32_t* __restrict__ bins,
                                uint32_t* __restrict__ order) {
   const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) order[atomicAdd(&bins[ragged_bin(off, i, block_bytes)], 1u)] = uint32_t(i);
+  if (i < n) order[atomicAdd(&bins[ragged_bin(off, i, block_units)], 1u)] = uint32_t(i);
 }
 
 // anemoi_probe_issue_rate: every lane runs ONE dependent chain of v_mad_u64_u32 -- the instruction that carries the
@@ -1145,21 +1145,30 @@ int anemoi_hash_bytes_dev(int field, int width, const void* d_msgs, size_t msg_l
   return ANEMOI_OK;
 }
 
-int anemoi_hash_bytes_ragged_dev(int field, int width, const void* d_msgs, const void* d_offsets, size_t n, void* d_out,
-                                 void* stream) {
+// the ragged sponge on device-resident messages: bytes (offsets in bytes) or ABI elements (offsets in elements)
+static int ragged_dev(int field, int width, int bytes, const void* d_msgs, const void* d_offsets, size_t n, void* d_out,
+                      void* stream) {
   int rc = check_instance(field, width);
   if (rc) return rc;
   if (n && (!d_out || !d_offsets || !d_msgs)) return ANEMOI_ERR_ARG;
   PermConsts pc;
   if ((rc = get_consts(field, width, &pc))) return rc;
-  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, d_msgs, d_offsets, n, d_out, pc, nullptr, (hipStream_t)stream));
+  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, bytes, d_msgs, d_offsets, n, d_out, pc, nullptr, (hipStream_t)stream));
   return ANEMOI_OK;
+}
+int anemoi_hash_bytes_ragged_dev(int field, int width, const void* d_msgs, const void* d_offsets, size_t n, void* d_out,
+                                 void* stream) {
+  return ragged_dev(field, width, 1, d_msgs, d_offsets, n, d_out, stream);
+}
+int anemoi_hash_field_ragged_dev(int field, int width, const void* d_elems, const void* d_offsets, size_t n, void* d_out,
+                                 void* stream) {
+  return ragged_dev(field, width, 0, d_elems, d_offsets, n, d_out, stream);
 }
 
 size_t anemoi_ragged_scratch_bytes(size_t n) { return (size_t(kRaggedBins) + n) * sizeof(uint32_t); }
 
-int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void* d_msgs, const void* d_offsets, size_t n,
-                                          void* d_out, void* d_scratch, size_t scratch_bytes, void* stream) {
+static int ragged_bucketed_dev(int field, int width, int bytes, const void* d_msgs, const void* d_offsets, size_t n, void* d_out,
+                               void* d_scratch, size_t scratch_bytes, void* stream) {
   int rc = check_instance(field, width);
   if (rc) return rc;
   if (n && (!d_out || !d_offsets || !d_msgs || !d_scratch)) return ANEMOI_ERR_ARG;
@@ -1171,15 +1180,24 @@ int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void* d_ms
   hipStream_t s = (hipStream_t)stream;
   uint32_t* bins = (uint32_t*)d_scratch;      // kRaggedBins counters, then the order: n message indices
   uint32_t* order = bins + kRaggedBins;
-  const uint32_t block_bytes = uint32_t(width - 1) * uint32_t(anemoi::field_ops(field)->chunk);   // bytes one permutation absorbs
+  // what one permutation absorbs, in the unit of the offsets: bytes, or elements
+  const uint32_t block_units = uint32_t(width - 1) * (bytes ? uint32_t(anemoi::field_ops(field)->chunk) : 1u);
   const unsigned grid = unsigned((n + 255) / 256);
   HIP_TRY(hipMemsetAsync(bins, 0, size_t(kRaggedBins) * sizeof(uint32_t), s));
-  k_ragged_hist<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, block_bytes, bins);
+  k_ragged_hist<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, block_units, bins);
   k_ragged_scan<<<1, 1024, 0, s>>>(bins);
-  k_ragged_place<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, block_bytes, bins, order);
+  k_ragged_place<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, block_units, bins, order);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, d_msgs, d_offsets, n, d_out, pc, order, s));
+  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, bytes, d_msgs, d_offsets, n, d_out, pc, order, s));
   return ANEMOI_OK;
+}
+int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void* d_msgs, const void* d_offsets, size_t n,
+                                          void* d_out, void* d_scratch, size_t scratch_bytes, void* stream) {
+  return ragged_bucketed_dev(field, width, 1, d_msgs, d_offsets, n, d_out, d_scratch, scratch_bytes, stream);
+}
+int anemoi_hash_field_ragged_bucketed_dev(int field, int width, const void* d_elems, const void* d_offsets, size_t n,
+                                          void* d_out, void* d_scratch, size_t scratch_bytes, void* stream) {
+  return ragged_bucketed_dev(field, width, 0, d_elems, d_offsets, n, d_out, d_scratch, scratch_bytes, stream);
 }
 
 int anemoi_merkle_root_dev(int field, const void* d_leaves, unsigned depth, void* d_scratch, void* d_root,
@@ -1297,8 +1315,11 @@ int anemoi_hash_bytes_batch(int field, int width, const uint8_t* msgs, size_t ms
   return sponge_host(field, width, 1, msgs, msg_len, n, out, device);
 }
 
-int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t* msgs, const uint64_t* offsets, size_t n,
-                                   uint64_t* out, int device) {
+// Sponge::hash / hash_field on n host messages of different lengths: bytes with byte offsets, or (bytes = 0) ABI
+// elements with offsets in ELEMENTS.  Everything below works on BYTE offsets (element offsets x the element size); the
+// offsets a chunk carries to the device are converted back to the kernel's unit.
+static int ragged_host(int field, int width, int bytes, const uint8_t* msgs, const uint64_t* offsets, size_t n, uint64_t* out,
+                       int device) {
   int rc = check_instance(field, width);
   if (rc) return rc;
   if (n && (!out || !offsets)) return ANEMOI_ERR_ARG;
@@ -1306,7 +1327,16 @@ int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t* msgs, co
   for (size_t i = 0; i < n; i++)
     if (offsets[i + 1] < offsets[i]) return ANEMOI_ERR_ARG;  // offsets must be non-decreasing
   if (offsets[n] > offsets[0] && !msgs) return ANEMOI_ERR_ARG;
-  const size_t eb = elem_bytes(field);
+  const size_t eb = elem_bytes(field), unit = bytes ? 1 : eb;
+  if (offsets[n] > UINT64_MAX / unit) return ANEMOI_ERR_ARG;
+  std::vector<uint64_t> scaled;   // element offsets as byte offsets
+  if (unit != 1) {
+    scaled.resize(n + 1);
+    for (size_t i = 0; i <= n; i++) scaled[i] = offsets[i] * unit;
+  }
+  const uint64_t* boff = unit == 1 ? offsets : scaled.data();
+  // bytes one permutation absorbs
+  const size_t block_bytes = size_t(width - 1) * (bytes ? size_t(anemoi::field_ops(field)->chunk) : eb);
   // Chunked like the fixed-length batches (rt::pipeline_staged): cut at message boundaries near the chunk
   // target, whole wavefronts of messages per chunk, offsets rebased to the chunk's first byte; the copy of
   // chunk c + 1 runs under the kernel of chunk c and the device holds three chunks, not the batch.
@@ -1315,14 +1345,13 @@ int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t* msgs, co
   return rt::for_devices(device, n, [&](int dev, size_t first, size_t count) -> int {
     if (!count) return ANEMOI_OK;
     return with_lane(dev, [&](Lane& ln) -> int {
-      const uint64_t* off = offsets + first;
+      const uint64_t* off = boff + first;
       const size_t quantum = quantum_of(field, anemoi::kKindSponge, width, dev);
       // Length bucketing: a wavefront costs what its longest message costs, and a realistic ragged batch arrives
       // unsorted.  The host walks every offset anyway, so messages are STAGED by descending block count (stable;
       // host::ragged_order returns nothing when the order as given is already within ~3 % of that) and the digests
       // are scattered back to the caller's order: per-message semantics unchanged (src/<f>/anemoi_x/hasher.rs hash()).
-      const std::vector<size_t> order =
-          host::ragged_order(off, count, size_t(width - 1) * size_t(anemoi::field_ops(field)->chunk), per_wave);
+      const std::vector<size_t> order = host::ragged_order(off, count, block_bytes, per_wave);
       std::vector<uint64_t> poff;     // offsets of the permuted sequence (virtual: the bytes are gathered while staging)
       if (!order.empty()) {
         poff.resize(count + 1);
@@ -1355,10 +1384,12 @@ int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t* msgs, co
                 if (len) memcpy(dst + rel[i], msgs + off[m], len);
               }
             }
+            if (unit != 1)   // the kernel reads offsets in elements
+              for (size_t i = 0; i <= cnt_of(c); i++) rel[i] /= unit;
             return ANEMOI_OK;
           },
           [&](size_t c, void* di, void* dout, void*, hipStream_t st) -> int {
-            return anemoi_hash_bytes_ragged_dev(field, width, (char*)di + off_bytes(c), di, cnt_of(c), dout, st);
+            return ragged_dev(field, width, bytes, (char*)di + off_bytes(c), di, cnt_of(c), dout, st);
           },
           [&](size_t c, const char* h) -> int {
             if (order.empty()) {
@@ -1371,6 +1402,14 @@ int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t* msgs, co
           });
     });
   });
+}
+int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t* msgs, const uint64_t* offsets, size_t n,
+                                   uint64_t* out, int device) {
+  return ragged_host(field, width, 1, msgs, offsets, n, out, device);
+}
+int anemoi_hash_field_ragged_batch(int field, int width, const uint64_t* elems, const uint64_t* offsets, size_t n,
+                                   uint64_t* out, int device) {
+  return ragged_host(field, width, 0, (const uint8_t*)elems, offsets, n, out, device);
 }
 
 int anemoi_to_montgomery(int field, const uint64_t* in, uint64_t* out, size_t count, int device) {

@@ -157,6 +157,19 @@ struct Instance {
                                          msgs.empty() ? nullptr : out[0].elements[0].limbs.data(), device));
     return out;
   }
+  // Sponge::hash_field of each of `msgs` (any numbers of elements) in one launch: item i == hash_field(msgs[i])
+  static std::vector<D> hash_field_ragged(const std::vector<std::vector<F>>& msgs, int device = 0) {
+    std::vector<uint64_t> off(msgs.size() + 1, 0);
+    for (size_t i = 0; i < msgs.size(); i++) off[i + 1] = off[i] + msgs[i].size();
+    std::vector<F> blob;
+    blob.reserve(off.back());
+    for (const auto& m : msgs) blob.insert(blob.end(), m.begin(), m.end());
+    std::vector<D> out(msgs.size());
+    static_assert(sizeof(F) == sizeof(uint64_t) * LIMBS, "an element is its limbs");
+    check(anemoi_hash_field_ragged_batch(FIELD, WIDTH, blob.empty() ? nullptr : blob[0].limbs.data(), off.data(), msgs.size(),
+                                         msgs.empty() ? nullptr : out[0].elements[0].limbs.data(), device));
+    return out;
+  }
   // n pairs of digests -> n digests, item i == merge(pairs[i]) (the 4-3 form keeps the reference's behaviour, see merge)
   static std::vector<D> merge_batch(const std::vector<std::array<D, 2>>& pairs, int device = 0) {
     std::vector<D> out(pairs.size());

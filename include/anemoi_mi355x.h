@@ -211,6 +211,11 @@ int anemoi_hash_bytes_batch(int field, int width, const uint8_t *msgs, size_t ms
  * the pre-sorted one). */
 int anemoi_hash_bytes_ragged_batch(int field, int width, const uint8_t *msgs, const uint64_t *offsets, size_t n,
                                    uint64_t *out, int device);
+/* Sponge::hash_field on n messages of DIFFERENT lengths: message i = elements [offsets[i], offsets[i+1]) of `elems`
+ * (n + 1 non-decreasing offsets counted in ELEMENTS; an empty message hashes to the digest of the zero state).  The same
+ * pipeline and the same bucketing by block count as the byte form. */
+int anemoi_hash_field_ragged_batch(int field, int width, const uint64_t *elems, const uint64_t *offsets, size_t n,
+                                   uint64_t *out, int device);
 
 /* Root of the binary Merkle tree over 2^depth leaf digests built with the 2-1 instance's merge,
  * level by level (depth 0 returns the leaf; depth <= 30).  With ANEMOI_ALL_DEVICES each GPU
@@ -310,6 +315,12 @@ int anemoi_hash_bytes_ragged_dev(int field, int width, const void *d_msgs, const
  * launches and one memset on `stream`: capturable like the other `_dev` functions. */
 size_t anemoi_ragged_scratch_bytes(size_t n);
 int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void *d_msgs, const void *d_offsets, size_t n, void *d_out,
+                                          void *d_scratch, size_t scratch_bytes, void *stream);
+/* The two calls above for messages of field elements (hash_field): d_elems = elements in ABI form (8-byte aligned),
+ * d_offsets = n + 1 uint64 offsets counted in ELEMENTS.  Same kernels, same routing, same scratch. */
+int anemoi_hash_field_ragged_dev(int field, int width, const void *d_elems, const void *d_offsets, size_t n, void *d_out,
+                                 void *stream);
+int anemoi_hash_field_ragged_bucketed_dev(int field, int width, const void *d_elems, const void *d_offsets, size_t n, void *d_out,
                                           void *d_scratch, size_t scratch_bytes, void *stream);
 /* d_scratch: at least 2^depth elements; d_root: 1 element; d_leaves is not modified. */
 int anemoi_merkle_root_dev(int field, const void *d_leaves, unsigned depth, void *d_scratch, void *d_root,

@@ -159,6 +159,15 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < msgs[3].size(); i++) msgs[3][i] = uint8_t(i * 31 + 5);
     auto got = I::hash_ragged(msgs);
     for (size_t i = 0; i < msgs.size(); i++) EXPECT(got[i] == I::hash(msgs[i]), "hash_ragged item");
+    // ... and hash_field over messages of 0, 1, 2, 3, 4, 7 elements (the digests above serve as elements)
+    std::vector<std::vector<I::F>> emsgs;
+    for (size_t k : {0, 1, 2, 3, 4, 7}) {
+      std::vector<I::F> m;
+      for (size_t i = 0; i < k; i++) m.push_back(got[(i + k) % got.size()].elements[0]);
+      emsgs.push_back(m);
+    }
+    auto egot = I::hash_field_ragged(emsgs);
+    for (size_t i = 0; i < emsgs.size(); i++) EXPECT(egot[i] == I::hash_field(emsgs[i]), "hash_field_ragged item");
     using J = AnemoiJubjub_2_1;
     std::vector<std::array<J::D, 2>> pairs(5);
     for (size_t i = 0; i < pairs.size(); i++) {

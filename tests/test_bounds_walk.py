@@ -50,23 +50,24 @@ def test_every_step_of_every_kernel_family_is_allowed(logs, params):
 LANE_FAMILIES = ["k_permutation<2>", "k_permutation<2,sbox_only>", "k_jive<2,2>", "k_exp_alpha", "k_exp_inv_alpha",
                  "k_sponge<2,bytes> whole", "k_sponge<2,bytes> first segment", "k_sponge<2,bytes> last segment",
                  "k_sponge<2,elements> whole", "k_sponge<2,elements> first segment", "k_sponge<2,elements> last segment",
-                 "k_sponge_ragged", "k_merkle_climb depth 3", "k_permutation<4> (one state per lane)",
+                 "k_sponge_ragged<bytes>", "k_sponge_ragged<elements>", "k_merkle_climb depth 3", "k_permutation<4> (one state per lane)",
                  "k_jive<4,2> (one state per lane)", "k_jive<4,4> (one state per lane)", "k_permutation_pair",
                  "k_permutation_pair<sbox_only>", "k_jive_pair<2>", "k_jive_pair<4>", "k_sponge_pair<bytes> whole",
                  "k_sponge_pair<bytes> first segment", "k_sponge_pair<bytes> last segment", "k_sponge_pair<elements> whole",
-                 "k_sponge_pair<elements> first segment", "k_sponge_pair<elements> last segment", "k_sponge_ragged_pair"]
+                 "k_sponge_pair<elements> first segment", "k_sponge_pair<elements> last segment", "k_sponge_ragged_pair<bytes>",
+                 "k_sponge_ragged_pair<elements>"]
 COOP_FAMILIES = ["k_jive2_coop<%s>", "k_permutation_coop<2,%s>", "k_merkle_climb_coop<%s> depth 3", "k_jive4_coop<2,%s>",
                  "k_jive4_coop<4,%s>", "k_permutation_coop<4,%s>"]
 for _w in (2, 4):
     COOP_FAMILIES += ["k_sponge_coop<%d,bytes,%%s> %s" % (_w, part) for part in ("whole", "first segment", "last segment")]
     COOP_FAMILIES += ["k_sponge_coop<%d,elements,%%s> %s" % (_w, part) for part in ("whole", "last segment")]
-    COOP_FAMILIES += ["k_sponge_ragged_coop<%d,%%s>" % _w]     # two messages of different lengths in one wavefront
+    COOP_FAMILIES += ["k_sponge_ragged_coop<%d,%s,%%s>" % (_w, kind) for kind in ("bytes", "elements")]   # two messages of different lengths in one wavefront
 
 
 def test_the_walk_covers_every_kernel_family(logs):
     want = ["lane " + c for c in LANE_FAMILIES] + ["lane run-time instance, NUM_COLUMNS = %d" % c for c in range(1, 17)]
     want += ["scan " + c % "16" for c in COOP_FAMILIES] + ["fold " + c % "32" for c in COOP_FAMILIES]
-    want += ["fold k_sponge_ragged_coop<4,32> short message"]   # (the 4-3 fold kernel holds one message per wavefront)
+    want += ["fold k_sponge_ragged_coop<4,%s,32> short message" % kind for kind in ("bytes", "elements")]   # (the 4-3 fold kernel holds one message per wavefront)
     for f, log in logs.items():
         assert sorted(log.cases) == sorted(want), FIELD_IDS[f]
         # ... and every arithmetic statement of the headers was reached on every field's walk where it exists

@@ -83,6 +83,17 @@ def test_argument_errors_need_no_device(A):
     assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 2, p, p, 4, q, big.ctypes.data + 2, big.nbytes - 2, None) == -3
     assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 2, p, p, 0, q, big.ctypes.data, big.nbytes, None) == 0   # nothing to do
     assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 3, p, p, 4, q, big.ctypes.data, big.nbytes, None) == -2
+    # ... the same checks in front of the hash_field forms; decreasing element offsets
+    assert L.anemoi_hash_field_ragged_bucketed_dev(0, 2, p, p, 4, q, None, 0, None) == -3
+    assert L.anemoi_hash_field_ragged_bucketed_dev(0, 2, p, p, 4, q, big.ctypes.data, 64, None) == -3
+    assert L.anemoi_hash_field_ragged_bucketed_dev(0, 2, p, p, 0, q, big.ctypes.data, big.nbytes, None) == 0
+    assert L.anemoi_hash_field_ragged_dev(7, 2, p, p, 4, q, None) == -1
+    assert L.anemoi_hash_field_ragged_dev(0, 6, p, p, 4, q, None) == -2
+    assert L.anemoi_hash_field_ragged_dev(0, 2, None, p, 4, q, None) == -3
+    offs = np.array([0, 3, 2], dtype=np.uint64)
+    assert L.anemoi_hash_field_ragged_batch(0, 2, p, offs.ctypes.data_as(_lib._u64p), 2, q, 0) == -3
+    assert L.anemoi_hash_field_ragged_batch(0, 2, p, offs.ctypes.data_as(_lib._u64p), 0, q, 0) == 0
+    assert L.anemoi_hash_field_ragged_batch(0, 2, None, np.array([0, 3], dtype=np.uint64).ctypes.data_as(_lib._u64p), 1, q, 0) == -3
     d = ctypes.c_double()
     assert L.anemoi_probe_issue_rate(0, None, ctypes.byref(d), ctypes.byref(d), ctypes.byref(d)) == -3
     with pytest.raises(A.AnemoiError):

@@ -356,6 +356,77 @@ def test_small_ragged_batches_on_every_kernel_family(A, oracle):
                         assert (got == want).all(), (field, width, name, "bucketed" if bucketed else "in order")
 
 
+def test_ragged_hash_field_on_every_kernel_family(A, oracle):
+    """anemoi_hash_field_ragged_batch / _dev / _bucketed_dev: Sponge::hash_field (src/traits.rs:14) on messages of
+    different NUMBERS OF ELEMENTS in one launch -- 0, 1, around the rate block, long next to short -- every field, both
+    widths, the fold / scan / lane-private routings forced, host entry point and both device forms; and a batch of
+    5 000 messages through the lane-private kernels at a real grid with the host path's bucketing.  Every digest = the
+    oracle's hash_field of that message alone; canonical all-ones-ish and zero elements included."""
+    import torch
+    from anemoi_amd import synth
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(616)
+    routes = {"fold": {}, "scan": dict(coop2d_max=0, coop2d43_max=0),
+              "lane-private": dict(coop2d_max=0, coop2d43_max=0, coop_sponge_max=0)}
+    for fid, field in enumerate(FIELD_IDS):
+        for width in (2, 4):
+            inst = A.Anemoi(field, width)
+            r, L = width - 1, inst.limbs
+            counts = [9, 0, 1, 2, 3, 4, r, r + 1, 2 * r, 2 * r + 1, 0, 14, 5] + [int(v) for v in rng.integers(0, 12, size=8)]   # 21 messages
+            pool = synth.elements(field, 900 + fid, 0, sum(counts) + 2)
+            pool[0] = 0                                       # the zero element; (p - 1 sits in the oracle goldens already)
+            msgs, at = [], 0
+            for c in counts:
+                msgs.append(pool[at:at + c])
+                at += c
+            want = np.stack([oracle.hash_field(fid, width, m) for m in msgs])
+            n = len(msgs)
+            offs = np.zeros(n + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum(counts, dtype=np.uint64)
+            d_blob = torch.from_numpy(np.concatenate(msgs + [pool[-1:]]).view(np.int64).reshape(-1)).to(dev)
+            d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+            need = A.lib.anemoi_ragged_scratch_bytes(n)
+            d_scr = torch.empty(need, dtype=torch.uint8, device=dev)
+            for name, opts in routes.items():
+                with A.options(**opts):
+                    assert (inst.hash_field_ragged(msgs) == want).all(), (field, width, name, "host")
+                    assert (inst.hash_field_ragged(msgs[:1]) == want[:1]).all()
+                    for bucketed in (0, 1):
+                        d_out = torch.zeros(n * L, dtype=torch.int64, device=dev)
+                        if bucketed:
+                            rc = A.lib.anemoi_hash_field_ragged_bucketed_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n,
+                                                                             d_out.data_ptr(), d_scr.data_ptr(), need, s)
+                        else:
+                            rc = A.lib.anemoi_hash_field_ragged_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n, d_out.data_ptr(), s)
+                        assert rc == 0
+                        torch.cuda.synchronize()
+                        got = d_out.cpu().numpy().view(np.uint64).reshape(n, L)
+                        assert (got == want).all(), (field, width, name, "bucketed" if bucketed else "in order")
+            assert len(inst.hash_field_ragged([])) == 0 and (inst.hash_field_ragged([pool[:0]])[0] == 0).all()
+    # a big unsorted batch: lane-private kernels, several wavefronts, host-side bucketing, also sharded over virtual devices
+    for field, width in (("bn_254", 4), ("bls12_381", 2)):
+        fid, inst = FIELD_IDS.index(field), A.Anemoi(field, width)
+        counts = [int(v) if rng.integers(0, 12) else int(v) * 9 for v in rng.integers(0, 9, size=5000)]
+        pool = synth.elements(field, 77, 0, sum(counts))
+        msgs, at = [], 0
+        for c in counts:
+            msgs.append(pool[at:at + c])
+            at += c
+        got = inst.hash_field_ragged(msgs)
+        for i in list(range(0, 5000, 211)) + [4999]:
+            assert (got[i] == oracle.hash_field(fid, width, msgs[i])).all(), (field, width, i, counts[i])
+        with virtual_devices(3):
+            assert (A.Anemoi(field, width, device=A.ALL_DEVICES).hash_field_ragged(msgs) == got).all()
+    # decreasing offsets are rejected before any device work
+    offs = np.array([0, 3, 2], dtype=np.uint64)
+    blob = np.zeros((4, 4), dtype=np.uint64)
+    out = np.zeros((2, 4), dtype=np.uint64)
+    from anemoi_amd import _lib
+    assert A.lib.anemoi_hash_field_ragged_batch(4, 2, blob.ctypes.data_as(_lib._u64p), offs.ctypes.data_as(_lib._u64p), 2,
+                                                out.ctypes.data_as(_lib._u64p), 0) == -3
+
+
 def test_unsorted_device_resident_ragged_batch_is_bucketed_on_the_device(A, oracle):
     """anemoi_hash_bytes_ragged_bucketed_dev: the device-side counting sort by block count in front of the ragged kernels
     (the device-resident counterpart of the host path's bucketing).  A long-tailed UNSORTED batch -- most messages short,
