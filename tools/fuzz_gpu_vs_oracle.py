@@ -6,7 +6,7 @@
   Jive 4-3      lane-pair, row-cooperative and two-row fold (one state per wavefront), k = 2 and 4
   permutation   the default routing of the batch size
   sponge        two-row / row-cooperative / lane-private kernels on equal-length batches, the three ragged kernels on all
-                lengths in one batch, the segment-fed host path (tiny forced segments)
+                lengths in one batch (byte messages, and hash_field's element messages), the segment-fed host path (tiny forced segments)
   generic       the run-time-instance kernels fed with the shipped constants (3 fields)
 
 Structured states stress carry patterns: limbs of all ones, values next to p and to 2^k, sparse values.  Kernels are
@@ -137,7 +137,18 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
                 ok = ok and (inst.hash_ragged(ragged) == np.concatenate(want)).all()
             with A.options(**LANE):
                 ok = ok and (inst.hash_ragged(ragged) == np.concatenate(want)).all()
-            log("%-16s W=%d sponge, %d lengths x 5 messages (default, row-coop, lane-private, segments; ragged on the three): %s"
+            # hash_field over element messages of structured values, 0 .. 3 rate blocks + 1 elements, all in one ragged batch
+            pval = int(params[field]["modulus"])
+            sv = structured_values(pval)
+            emsgs = [oracle.ints_to_mont(fid, [sv[(7 * k + i) % len(sv)] for i in range(k)]).reshape(k, inst.limbs)
+                     for k in list(range(0, 3 * r + 2)) * 3]
+            ewant = np.stack([oracle.hash_field(fid, width, m) for m in emsgs])
+            ok = ok and (inst.hash_field_ragged(emsgs) == ewant).all()
+            with A.options(coop2d_max=0, coop2d43_max=0):
+                ok = ok and (inst.hash_field_ragged(emsgs) == ewant).all()
+            with A.options(**LANE):
+                ok = ok and (inst.hash_field_ragged(emsgs) == ewant).all()
+            log("%-16s W=%d sponge, %d lengths x 5 messages (default, row-coop, lane-private, segments; ragged bytes and ragged elements on the three): %s"
                 % (field, width, len(lens), check(ok, (field, width, "sponge"))))
     if generic:   # the run-time-instance kernels fed with the shipped constants reproduce the fixed instances
         for field in ("bn_254", "bls12_381", "ed_on_bls12_377"):
