@@ -464,13 +464,16 @@ __global__ void k_assemble4(const uint4* __restrict__ cur, const uint4* __restri
 // A wavefront of the ragged sponge kernels runs as many rate-blocks as its LONGEST message; host::ragged_order (the host
 // path's bucketing, host_logic.h) is the specification: messages by descending block count.  Here as a counting sort on
 // the device: histogram of the block counts (clamped to kRaggedBins - 1: longer messages share the first bucket),
-// exclusive scan from the longest bucket down, placement by atomic cursor.  Not stable -- equal block counts land in
+// exclusive scan from the longest bucket down, placement by atomic cursor (four launches, nothing else).  Not stable -- equal block counts land in
 // any order, which costs nothing -- and every digest goes back to its message's own index.
 constexpr int kRaggedBins = 1 << 16;
 __device__ __forceinline__ uint32_t ragged_bin(const uint64_t* __restrict__ off, size_t i, uint32_t block_units) {
   const uint64_t blocks = (off[i + 1] - off[i] + block_units - 1) / block_units;
   return uint32_t(kRaggedBins - 1) - uint32_t(blocks < uint64_t(kRaggedBins - 1) ? blocks : uint64_t(kRaggedBins - 1));   // bin 0 = the longest
 }
+// (a kernel, not hipMemsetAsync: captured into a hipGraph, the memset node in front of these kernels did not zero the
+// counters on replay -- the second replay then placed its indices behind the first one's and wrote past the scratch)
+__global__ void k_ragged_zero(uint32_t* __restrict__ bins) { bins[size_t(blockIdx.x) * blockDim.x + threadIdx.x] = 0; }
 __global__ void k_ragged_hist(const uint64_t* __restrict__ off, size_t n, uint32_t block_units, uint32_t* __restrict__ bins) {
   const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) atomicAdd(&bins[ragged_bin(off, i, block_units)], 1u);
@@ -1183,7 +1186,8 @@ static int ragged_bucketed_dev(int field, int width, int bytes, const void* d_ms
   // what one permutation absorbs, in the unit of the offsets: bytes, or elements
   const uint32_t block_units = uint32_t(width - 1) * (bytes ? uint32_t(anemoi::field_ops(field)->chunk) : 1u);
   const unsigned grid = unsigned((n + 255) / 256);
-  HIP_TRY(hipMemsetAsync(bins, 0, size_t(kRaggedBins) * sizeof(uint32_t), s));
+  static_assert(kRaggedBins % 256 == 0, "k_ragged_zero: whole workgroups");
+  k_ragged_zero<<<kRaggedBins / 256, 256, 0, s>>>(bins);
   k_ragged_hist<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, block_units, bins);
   k_ragged_scan<<<1, 1024, 0, s>>>(bins);
   k_ragged_place<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, block_units, bins, order);

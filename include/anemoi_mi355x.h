@@ -39,8 +39,10 @@
  * STREAM CAPTURE: once its instance is initialised, every `_dev` function only launches kernels (a depth-0 tree: one
  * asynchronous device-to-device copy) on the stream it is handed, so it may be captured into a hipGraph; the options below
  * are read on the HOST when the call is made, so a graph keeps the kernels chosen at capture time whatever the options
- * become later (tests/test_gpu_capture.py).  Not capturable: anemoi_init / anemoi_warmup / anemoi_release /
- * anemoi_probe_issue_rate, anemoi_generic_prepare / _destroy, and every host-pointer function (they copy and wait).
+ * become later (tests/test_gpu_capture.py).  No `_dev` function issues a hipMemsetAsync: on ROCm 7.2 a captured memset
+ * node takes effect on the first replay only (profiles/r05/captured_memset_node_replays.txt).  Not capturable:
+ * anemoi_init / anemoi_warmup / anemoi_release / anemoi_probe_issue_rate, anemoi_clock_sampler_*, anemoi_generic_prepare /
+ * _destroy, and every host-pointer function (they copy and wait).
  *
  * OPTIONS: the kernel-selection cut-offs and the test / diagnostic knobs are listed with anemoi_set_option below.
  * Each is read from its environment variable ONCE (first use) and changed afterwards only through the API; no entry
@@ -309,10 +311,10 @@ int anemoi_hash_bytes_dev(int field, int width, const void *d_msgs, size_t msg_l
 int anemoi_hash_bytes_ragged_dev(int field, int width, const void *d_msgs, const void *d_offsets, size_t n, void *d_out,
                                  void *stream);
 /* The same on an UNSORTED device-resident batch: the library first orders the messages by descending block count on the
- * device (a counting sort: histogram, scan, placement -- three small launches on `stream`), runs the ragged kernels in
+ * device (a counting sort: zero, histogram, scan, placement -- four small launches on `stream`), runs the ragged kernels in
  * that order and writes every digest to its message's own index.  d_scratch: anemoi_ragged_scratch_bytes(n) bytes of
  * device memory the caller owns (65 536 counters + n 32-bit indices; 4-byte aligned), contents undefined afterwards; n < 2^32.  Only
- * launches and one memset on `stream`: capturable like the other `_dev` functions. */
+ * kernel launches on `stream`: capturable like the other `_dev` functions (tests/test_gpu_capture.py replays it). */
 size_t anemoi_ragged_scratch_bytes(size_t n);
 int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void *d_msgs, const void *d_offsets, size_t n, void *d_out,
                                           void *d_scratch, size_t scratch_bytes, void *stream);

@@ -2,12 +2,17 @@
 synchronise -- except that the FIRST use of a (device, field, width) uploads that instance's constant tables with a
 blocking copy (not legal inside a stream capture): call anemoi_init() beforehand").
 
-After anemoi_init, three calls are captured into ONE hipGraph on a side stream (torch.cuda.graph is plumbing: the
+After anemoi_init, four calls are captured into ONE hipGraph on a side stream (torch.cuda.graph is plumbing: the
 library only ever sees the hipStream_t it is handed):
   * anemoi_merkle_root_dev, depth 15 Jubjub: a chain of 15 launches that picks three different kernels by level size --
     lane-private (2^14 nodes), the row-cooperative scan (8 192, 4 096) and the two-row fold (2 048 ... 1);
   * anemoi_hash_bytes_dev (BN-254 Anemoi-4-3, 700 messages of 200 bytes: the two-row fold sponge);
-  * anemoi_jive_compress_k_dev (BLS12-381, 20 000 states: the lane-private throughput kernel).
+  * anemoi_jive_compress_k_dev (BLS12-381, 20 000 states: the lane-private throughput kernel);
+  * anemoi_hash_bytes_ragged_bucketed_dev (Jubjub, 300 messages of 0 ... 400 bytes: the four bucketing launches and the
+    ragged latency kernel reading the order they wrote.  Round 5 found a bug here: the counters were zeroed with
+    hipMemsetAsync, and the captured memset node did not zero them on replay -- every replay placed its indices behind
+    the previous one's and the third or fourth wrote past the scratch; they are zeroed by a kernel now, and the test
+    checks after every replay that the order array is a permutation of 0 ... n - 1).
 The graph is replayed three times on FRESH inputs written into the captured buffers, every output compared with the
 oracle.  Then the cut-offs are changed through anemoi_set_option -- which would send the same sizes to other kernels --
 and the captured graph must still give the right bits: capture froze the kernel CHOICE made at capture time (the
@@ -28,7 +33,7 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(21)
     jub, bn, bls = FIELD_IDS.index("jubjub"), FIELD_IDS.index("bn_254"), FIELD_IDS.index("bls12_381")
-    depth, nmsg, mlen, nst = 15, 700, 200, 20000
+    depth, nmsg, mlen, nst, nrag = 15, 700, 200, 20000, 300
     for f, w in ((jub, 2), (bn, 4), (bls, 2)):
         assert A.lib.anemoi_init(0, f, w) == 0          # constant tables up front: nothing but launches below
 
@@ -37,6 +42,21 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
         msgs = rng.integers(0, 256, size=(nmsg, mlen), dtype=np.uint8)
         states = rng.integers(0, 1 << 60, size=(nst, 2, 6), dtype=np.uint64)
         return leaves, msgs, states
+
+    # the ragged batch: the lengths stay (offsets are captured data like everything else), the bytes change per replay
+    rag_lens = rng.integers(0, 400, size=nrag)
+    rag_offs = np.zeros(nrag + 1, dtype=np.uint64)
+    rag_offs[1:] = np.cumsum(rag_lens, dtype=np.uint64)
+    d_rag_offs = torch.from_numpy(rag_offs.view(np.int64)).to(dev)
+    d_rag = torch.zeros(int(rag_offs[-1]) + 1, dtype=torch.uint8, device=dev)
+    d_rag_out = torch.zeros(nrag * 4, dtype=torch.int64, device=dev)
+    rag_need = A.lib.anemoi_ragged_scratch_bytes(nrag)
+    d_rag_scr = torch.empty(rag_need, dtype=torch.uint8, device=dev)
+    rag = {}
+
+    def fresh_ragged():
+        rag["blob"] = rng.integers(0, 256, size=int(rag_offs[-1]) + 1, dtype=np.uint8)
+        d_rag.copy_(torch.from_numpy(rag["blob"]).to(dev))
 
     def i64(a):
         return torch.from_numpy(a.view(np.int64).reshape(-1)).to(dev)
@@ -53,6 +73,8 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
         assert A.lib.anemoi_merkle_root_dev(jub, d_leaves.data_ptr(), depth, d_scratch.data_ptr(), d_root.data_ptr(), s) == 0
         assert A.lib.anemoi_hash_bytes_dev(bn, 4, d_msgs.data_ptr(), mlen, nmsg, d_dig.data_ptr(), s) == 0
         assert A.lib.anemoi_jive_compress_k_dev(bls, 2, 2, d_states.data_ptr(), d_out.data_ptr(), nst, s) == 0
+        assert A.lib.anemoi_hash_bytes_ragged_bucketed_dev(jub, 2, d_rag.data_ptr(), d_rag_offs.data_ptr(), nrag, d_rag_out.data_ptr(),
+                                                           d_rag_scr.data_ptr(), rag_need, s) == 0
 
     def check(what):
         torch.cuda.synchronize()
@@ -62,7 +84,14 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
         assert (got_dig == oracle.hash_bytes_batch(bn, 4, msgs, threads=8)).all(), what + ": sponge digests"
         got_out = d_out.cpu().numpy().view(np.uint64).reshape(nst, 6)
         assert (got_out == oracle.compress_batch(bls, 2, states, threads=8).reshape(nst, 6)).all(), what + ": Jive outputs"
+        got_rag = d_rag_out.cpu().numpy().view(np.uint64).reshape(nrag, 4)
+        order = d_rag_scr.cpu().numpy()[65536 * 4:].view(np.uint32)
+        assert sorted(order.tolist()) == list(range(nrag)), what + ": the bucketing's order is not a permutation"
+        for i in range(0, nrag, 7):
+            m = rag["blob"][int(rag_offs[i]):int(rag_offs[i + 1])].tobytes()
+            assert (got_rag[i] == oracle.hash_bytes(jub, 2, m)).all(), what + ": ragged digest %d" % i
 
+    fresh_ragged()
     side = torch.cuda.Stream()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=side):
@@ -71,7 +100,7 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
         if replay:
             leaves, msgs, states = fresh()
             d_leaves.copy_(i64(leaves)), d_msgs.copy_(torch.from_numpy(msgs.reshape(-1)).to(dev)), d_states.copy_(i64(states))
-        d_root.zero_(), d_dig.zero_(), d_out.zero_()
+        d_root.zero_(), d_dig.zero_(), d_out.zero_(), d_rag_out.zero_(), fresh_ragged()
         graph.replay()
         check("replay %d" % replay)
 
@@ -79,12 +108,12 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
     with A.options(coop2d_max=0, coop2d43_max=0, coop4_max=0, coop43_max=0, coop_sponge_max=0):
         leaves, msgs, states = fresh()
         d_leaves.copy_(i64(leaves)), d_msgs.copy_(torch.from_numpy(msgs.reshape(-1)).to(dev)), d_states.copy_(i64(states))
-        d_root.zero_(), d_dig.zero_(), d_out.zero_()
+        d_root.zero_(), d_dig.zero_(), d_out.zero_(), d_rag_out.zero_(), fresh_ragged()
         graph.replay()                                   # still the kernels chosen at capture time
         check("replay after the options changed")
-        d_root.zero_(), d_dig.zero_(), d_out.zero_()
+        d_root.zero_(), d_dig.zero_(), d_out.zero_(), d_rag_out.zero_(), fresh_ragged()
         enqueue(torch.cuda.current_stream())             # a direct call takes the new route
         check("direct call on the new route")
-    d_root.zero_(), d_dig.zero_(), d_out.zero_()
+    d_root.zero_(), d_dig.zero_(), d_out.zero_(), d_rag_out.zero_(), fresh_ragged()
     graph.replay()
     check("replay after the options were restored")
