@@ -117,3 +117,105 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
     d_root.zero_(), d_dig.zero_(), d_out.zero_(), d_rag_out.zero_(), fresh_ragged()
     graph.replay()
     check("replay after the options were restored")
+
+
+def test_every_other_dev_entry_point_replays_like_a_direct_call(oracle, params):
+    """The rest of the `_dev` API in ONE captured graph -- permutation (in place), sbox_layer, hash_field, the retained
+    Merkle tree (a device-to-device copy node in front of its launches), path climbing, both Montgomery conversions, the
+    three remaining ragged forms (bytes in order, elements in order, elements bucketed) and the four entry points of a
+    prepared run-time instance -- replayed three times on fresh inputs: every output must equal what the same calls give
+    when made directly on the same inputs (the direct calls are what the rest of the suite checks against the oracle; one
+    output is checked against it here as well), and must not be the zeros the buffers held before."""
+    import torch
+    import anemoi_amd as A
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(88)
+    jub = FIELD_IDS.index("jubjub")
+    L, n, depth, epm = 4, 300, 7, 5
+    for w in (2, 4):
+        assert A.lib.anemoi_init(0, jub, w) == 0
+    ins = params["jubjub"]["instances"]["anemoi_2_1"]
+    enc = lambda vals: oracle.ints_to_mont(jub, [int(v) for v in vals])
+    prep = A.GenericAnemoi("jubjub", 1, ins["num_rounds"], enc(ins["ark_c"]), enc(ins["ark_d"])).prepare()
+
+    def elems(*shape):
+        return rng.integers(0, 1 << 60, size=shape + (L,), dtype=np.uint64)      # limbs < 2^60: canonical
+
+    counts = rng.integers(0, 9, size=n)
+    eoffs = np.zeros(n + 1, dtype=np.uint64)
+    eoffs[1:] = np.cumsum(counts, dtype=np.uint64)
+    blens = rng.integers(0, 200, size=n)
+    boffs = np.zeros(n + 1, dtype=np.uint64)
+    boffs[1:] = np.cumsum(blens, dtype=np.uint64)
+    host = {}
+
+    def fresh():
+        host.update(perm=elems(n, 2), sbox=elems(n, 4), hf=elems(n, epm), leaves=elems(1 << depth), climb_leaves=elems(n),
+                    paths=elems(n, depth), mont=elems(n), relems=elems(int(eoffs[-1]) + 1),
+                    rbytes=rng.integers(0, 256, size=int(boffs[-1]) + 1, dtype=np.uint8), gmsgs=rng.integers(0, 256, size=(n, 77), dtype=np.uint8))
+
+        host["gperm"] = host["perm"].copy()      # the run-time instance holds the shipped constants: same permutation
+
+    fresh()
+    t64 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).reshape(-1)).to(dev)
+    zeros = lambda k: torch.zeros(k * L, dtype=torch.int64, device=dev)
+    d = {k: (torch.from_numpy(v.reshape(-1)).to(dev) if v.dtype == np.uint8 else t64(v)) for k, v in host.items()}
+    d_index = t64(rng.integers(0, 1 << depth, size=n, dtype=np.uint64))
+    d_eoffs, d_boffs = t64(eoffs), t64(boffs)
+    need = A.lib.anemoi_ragged_scratch_bytes(n)
+    d_scr = torch.empty(need, dtype=torch.uint8, device=dev)
+    out = dict(hf=zeros(n), tree=zeros(2 << depth), roots=zeros(n), to_m=zeros(n), from_m=zeros(n), rb=zeros(n), re=zeros(n),
+               reb=zeros(n), gjive=zeros(n), ghf=zeros(n), ghb=zeros(n))
+    p = lambda t: t.data_ptr()
+    lib = A.lib
+
+    def enqueue(stream):
+        s = stream.cuda_stream
+        assert lib.anemoi_permutation_dev(jub, 2, p(d["perm"]), n, s) == 0
+        assert lib.anemoi_sbox_layer_dev(jub, 4, p(d["sbox"]), n, s) == 0
+        assert lib.anemoi_hash_field_dev(jub, 4, p(d["hf"]), epm, n, p(out["hf"]), s) == 0
+        assert lib.anemoi_merkle_tree_dev(jub, p(d["leaves"]), depth, p(out["tree"]), s) == 0
+        assert lib.anemoi_merkle_climb_dev(jub, p(d["climb_leaves"]), p(d_index), p(d["paths"]), depth, n, p(out["roots"]), s) == 0
+        assert lib.anemoi_from_montgomery_dev(jub, p(d["mont"]), p(out["from_m"]), n, s) == 0
+        assert lib.anemoi_to_montgomery_dev(jub, p(out["from_m"]), p(out["to_m"]), n, s) == 0
+        assert lib.anemoi_hash_bytes_ragged_dev(jub, 2, p(d["rbytes"]), p(d_boffs), n, p(out["rb"]), s) == 0
+        assert lib.anemoi_hash_field_ragged_dev(jub, 4, p(d["relems"]), p(d_eoffs), n, p(out["re"]), s) == 0
+        assert lib.anemoi_hash_field_ragged_bucketed_dev(jub, 2, p(d["relems"]), p(d_eoffs), n, p(out["reb"]), p(d_scr), need, s) == 0
+        prep.permutation_dev(p(d["gperm"]), n, s)
+        prep.compress_k_dev(2, p(d["perm"]), p(out["gjive"]), n, s)       # (reads what anemoi_permutation_dev left in place)
+        prep.hash_field_dev(1, p(d["hf"]), epm, n, p(out["ghf"]), s)
+        prep.hash_bytes_dev(1, p(d["gmsgs"]), 77, n, p(out["ghb"]), s)
+
+    def load():
+        for k, v in host.items():
+            d[k].copy_(torch.from_numpy(v.reshape(-1)).to(dev) if v.dtype == np.uint8 else t64(v))
+        for t in out.values():
+            t.zero_()
+
+    def collect():
+        torch.cuda.synchronize()
+        got = {k: t.cpu().numpy().copy() for k, t in out.items()}
+        got.update(perm=d["perm"].cpu().numpy().copy(), sbox=d["sbox"].cpu().numpy().copy(), gperm=d["gperm"].cpu().numpy().copy())
+        return got
+
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        enqueue(torch.cuda.current_stream())
+    for replay in range(3):
+        fresh()
+        load()
+        graph.replay()
+        got = collect()
+        load()
+        enqueue(torch.cuda.current_stream())
+        want = collect()
+        for k in want:
+            assert (got[k] == want[k]).all(), "replay %d: %s differs from the direct call" % (replay, k)
+            assert got[k].any(), k
+        assert (got["to_m"].view(np.uint64).reshape(n, L) == host["mont"]).all()          # from_montgomery then to_montgomery
+        i = int(np.argmax(counts))
+        m = host["relems"][int(eoffs[i]):int(eoffs[i + 1])]
+        assert (got["re"].view(np.uint64).reshape(n, L)[i] == oracle.hash_field(jub, 4, m)).all()
+        assert (got["reb"].view(np.uint64).reshape(n, L)[i] == oracle.hash_field(jub, 2, m)).all()
+        assert (got["perm"] == got["gperm"]).all()          # fixed instance = run-time instance fed with its constants
