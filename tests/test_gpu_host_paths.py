@@ -187,3 +187,64 @@ def test_few_long_messages_stay_segmented_and_bound_the_device_footprint(A, orac
     for i in (0, 1, n // 2, n - 1):
         assert (got[i] == oracle.hash_bytes(fid, width, msgs[i].tobytes())).all(), i
     A.release(0)
+
+
+def test_mixed_entry_points_from_many_threads_while_the_cut_offs_change(A, oracle):
+    """Seven host threads, each hammering a different host-pointer entry point (small and chunked Jive batches, both
+    sponges, both ragged forms, a Merkle root, a permutation) on different fields, while an eighth flips the
+    kernel-selection cut-offs back and forth: every call must return what the same call returned single-threaded
+    (the options choose kernels, never results; lanes, pools and constant tables are shared state).  One result of each
+    kind is also checked against the oracle."""
+    import threading
+    import time
+    rng = np.random.default_rng(2026)
+    el = lambda *shape: rng.integers(0, 1 << 60, size=shape, dtype=np.uint64)
+    jub, bn, bls, ves = (A.Anemoi(f, w) for f, w in (("jubjub", 2), ("bn_254", 4), ("bls12_381", 2), ("vesta", 4)))
+    msgs = [rng.integers(0, 256, size=int(k), dtype=np.uint8).tobytes() for k in rng.integers(0, 500, size=700)]
+    emsgs = [el(int(k), 4) for k in rng.integers(0, 9, size=500)]
+    jobs = {
+        "jive small": (lambda s=el(300, 2, 4): jub.compress_batch(s)),
+        "jive chunked": (lambda s=el(200000, 2, 6): bls.compress_batch(s)),
+        "sponge bytes": (lambda m=rng.integers(0, 256, size=(900, 333), dtype=np.uint8): bn.hash_batch(m)),
+        "sponge elements": (lambda e=el(3000, 7, 4): ves.hash_field_batch(e)),
+        "ragged bytes": (lambda: jub.hash_ragged(msgs)),
+        "ragged elements": (lambda: bn.hash_field_ragged(emsgs)),
+        "merkle root": (lambda lv=el(1 << 12, 4): jub.merkle_root(lv, 12)),
+        "permutation": (lambda s=el(5000, 4, 4): ves.permutation_batch(s)),
+    }
+    want = {k: np.array(f()) for k, f in jobs.items()}
+    fid = FIELD_IDS.index("jubjub")
+    assert (want["ragged bytes"][5] == oracle.hash_bytes(fid, 2, msgs[5])).all()
+    assert (want["ragged elements"][7] == oracle.hash_field(FIELD_IDS.index("bn_254"), 4, emsgs[7])).all()
+    errs, stop = [], threading.Event()
+
+    def worker(name):
+        try:
+            for _ in range(4):
+                if not (np.array(jobs[name]()) == want[name]).all():
+                    errs.append(name)
+        except Exception as e:      # noqa: BLE001 -- any error in a thread is a failure of the test
+            errs.append("%s: %r" % (name, e))
+
+    def flipper():
+        keys = ("coop2d_max", "coop2d43_max", "coop4_max", "coop43_max", "coop_sponge_max")
+        saved = {k: A.get_option(k) for k in keys}
+        i = 0
+        while not stop.is_set():
+            for k in keys:
+                A.set_option(k, 0 if i % 2 == 0 else saved[k])
+            i += 1
+            time.sleep(0.002)
+        for k in keys:
+            A.set_option(k, saved[k])
+
+    fl = threading.Thread(target=flipper)
+    fl.start()
+    ths = [threading.Thread(target=worker, args=(k,)) for k in jobs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    stop.set()
+    fl.join()
+    assert not errs, errs
