@@ -29,6 +29,15 @@ def test_every_path_the_documents_name_exists():
     assert not missing, "\n".join(sorted(set(missing)))
 
 
+def test_every_profile_the_index_lists_exists():
+    """profiles/README.md names its files relative to profiles/: `r05/host_api.txt`"""
+    text = open(os.path.join(ROOT, "profiles", "README.md")).read()
+    names = set(re.findall(r"`(r0\d/[\w./-]*\w\.(?:txt|json|csv|md))`", text))
+    assert len(names) > 80
+    missing = sorted(n for n in names if not os.path.exists(os.path.join(ROOT, "profiles", n)))
+    assert not missing, missing
+
+
 def test_kernel_source_comments_name_existing_files():
     missing = []
     csrc = os.path.join(ROOT, "anemoi-rust_amd", "csrc")
