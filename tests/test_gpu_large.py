@@ -119,3 +119,34 @@ def test_ragged_batch_with_offsets_beyond_4_gib_host_and_device(A, oracle):
     for r in range(reps):
         for name, o in (("host", got), ("device, in order", outs[0]), ("device, bucketed", outs[1])):
             assert (o[r * P:(r + 1) * P] == want).all(), "%s path, repeat %d" % (name, r)
+
+
+def test_merkle_root_over_more_than_4_gib_of_leaves(A, oracle):
+    """2^28 Jubjub leaves = 8 GiB + the levels above: the root from ONE call (host leaves, level by level on the device)
+    must equal the root over the 256 depth-20 subtree roots that 256 separate calls give (each on a 32 MiB slice, far
+    from any 32-bit limit), the top eight levels finished by the oracle; the device entry point likewise (leaves and
+    scratch resident: two 8 GiB buffers).  Leaves: 2^24 random elements repeated 16 times, the repeat number added to
+    limb 0 -- every depth-20 subtree is different."""
+    import torch
+    fid, inst = FIELD_IDS.index("jubjub"), A.Anemoi("jubjub", 2)
+    rng = np.random.default_rng(44)
+    depth, sub, rep = 28, 20, 24
+    base = rng.integers(0, 1 << 60, size=(1 << rep, 4), dtype=np.uint64)
+    leaves = np.tile(base, (1 << (depth - rep), 1))
+    leaves[:, 0] += np.repeat(np.arange(1 << (depth - rep), dtype=np.uint64), 1 << rep)
+    assert leaves.nbytes == 2 * GIB4
+    root = inst.merkle_root(leaves, depth)
+    roots = np.stack([inst.merkle_root(leaves[i << sub:(i + 1) << sub], sub) for i in range(1 << (depth - sub))])
+    assert len({r.tobytes() for r in roots}) == len(roots)
+    assert (root == oracle.merkle_root(fid, roots, depth - sub)).all()
+    dev = torch.device("cuda", 0)
+    d_leaves = torch.from_numpy(leaves.view(np.int64).reshape(-1)).to(dev)
+    del leaves
+    d_scratch = torch.empty((1 << depth) * 4, dtype=torch.int64, device=dev)
+    d_root = torch.zeros(4, dtype=torch.int64, device=dev)
+    assert A.lib.anemoi_merkle_root_dev(fid, d_leaves.data_ptr(), depth, d_scratch.data_ptr(), d_root.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert (d_root.cpu().numpy().view(np.uint64) == root).all()
+    del d_leaves, d_scratch
+    torch.cuda.empty_cache()
