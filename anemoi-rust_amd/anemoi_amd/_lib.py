@@ -70,6 +70,7 @@ _SIGS = {
     "anemoi_probe_issue_rate": ([_int] + [ctypes.POINTER(ctypes.c_double)] * 4, _int),
     "anemoi_clock_sampler_bytes": ([], _sz),
     "anemoi_clock_sampler_start_dev": ([_vp, _sz, ctypes.c_uint, ctypes.c_uint, _vp], _int),
+    "anemoi_clock_sampler_wait_dev": ([_vp, ctypes.c_uint, _vp], _int),
     "anemoi_clock_sampler_stop_dev": ([_vp, _vp], _int),
     "anemoi_clock_stamp_dev": ([_vp, _vp], _int),
     "anemoi_clock_sampler_read": ([_vp, _sz, ctypes.c_ulonglong, ctypes.c_ulonglong] + [ctypes.POINTER(ctypes.c_double)] * 3
@@ -186,7 +187,9 @@ class ClockSampler:
         self.side, self.third = torch.cuda.Stream(device), torch.cuda.Stream(device)
 
     def start(self, work_stream):
+        self.side.wait_stream(self.torch.cuda.current_stream())     # (the buffers were zero-filled on the current stream)
         _check(lib.anemoi_clock_sampler_start_dev(self.buf.data_ptr(), self.bytes, self.period_us, self.max_ms, self.side.cuda_stream))
+        _check(lib.anemoi_clock_sampler_wait_dev(self.buf.data_ptr(), 50, work_stream.cuda_stream))   # the work starts once the sampler runs
         _check(lib.anemoi_clock_stamp_dev(self.stamps.data_ptr(), work_stream.cuda_stream))
 
     def finish(self, work_stream):

@@ -570,6 +570,20 @@ struct SamplerBuf {
   uint64_t reserved;
   SamplerGroup g[kSamplerGroups];
 };
+// (kernels, not hipMemsetAsync, set the log up and stop it: fewer operations in front of the sampler, and see k_ragged_zero)
+__global__ __launch_bounds__(64) void k_sampler_init(SamplerBuf* buf) {
+  if (threadIdx.x == 0) buf->stop = 0, buf->groups = kSamplerGroups, buf->reserved = 0;   // reserved: 1 once the sampler runs
+  if (threadIdx.x < kSamplerGroups) buf->g[threadIdx.x].count = 0, buf->g[threadIdx.x].xcc = 0;
+}
+__global__ void k_sampler_stop(SamplerBuf* buf) { __hip_atomic_store(&buf->stop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// holds the CALLER's stream until the sampler has taken its first sample (or timeout): without it a sampler whose
+// stream is slow to start -- a queue created on first use -- can begin after a short piece of work has already ended
+__global__ void k_sampler_wait(SamplerBuf* buf, uint64_t max_ticks) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while (__hip_atomic_load(&buf->reserved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 &&
+         __builtin_amdgcn_s_memrealtime() - t0 < max_ticks)
+    __builtin_amdgcn_s_sleep(32);
+}
 __global__ __launch_bounds__(64) void k_clock_sampler(SamplerBuf* buf, uint32_t period_ticks, uint64_t max_ticks) {
   if (threadIdx.x) return;
   SamplerGroup& g = buf->g[blockIdx.x];
@@ -588,6 +602,7 @@ __global__ __launch_bounds__(64) void k_clock_sampler(SamplerBuf* buf, uint32_t 
       g.rec[n][1] = __builtin_amdgcn_s_memtime();
       n++;
       next += period_ticks;
+      if (n == 1 && blockIdx.x == 0) __hip_atomic_store(&buf->reserved, uint64_t(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (last || n >= uint32_t(kSamplerMaxRecords)) break;
     __builtin_amdgcn_s_sleep(100);   // ~6 400 cycles: the sampler takes an issue slot every few microseconds
@@ -802,17 +817,23 @@ int anemoi_clock_sampler_start_dev(void* d_buf, size_t bytes, unsigned period_us
       max_ms < 1 || max_ms > 600000)
     return ANEMOI_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(d_buf, 0, offsetof(SamplerBuf, g), s));                    // stop = 0
-  for (int i = 0; i < kSamplerGroups; i++)                                            // count = 0 of every group
-    HIP_TRY(hipMemsetAsync(&((SamplerBuf*)d_buf)->g[i], 0, 8, s));
+  k_sampler_init<<<1, 64, 0, s>>>((SamplerBuf*)d_buf);                                // stop = 0, every group's count = 0
   k_clock_sampler<<<kSamplerGroups, 64, 0, s>>>((SamplerBuf*)d_buf, period_us * 100u, uint64_t(max_ms) * 100000ull);
+  HIP_TRY(hipGetLastError());
+  return ANEMOI_OK;
+}
+
+int anemoi_clock_sampler_wait_dev(void* d_buf, unsigned timeout_ms, void* stream) {
+  if (!d_buf || timeout_ms < 1 || timeout_ms > 10000) return ANEMOI_ERR_ARG;
+  k_sampler_wait<<<1, 1, 0, (hipStream_t)stream>>>((SamplerBuf*)d_buf, uint64_t(timeout_ms) * 100000ull);
   HIP_TRY(hipGetLastError());
   return ANEMOI_OK;
 }
 
 int anemoi_clock_sampler_stop_dev(void* d_buf, void* stream) {
   if (!d_buf) return ANEMOI_ERR_ARG;
-  HIP_TRY(hipMemsetAsync(d_buf, 1, sizeof(uint32_t), (hipStream_t)stream));           // stop != 0
+  k_sampler_stop<<<1, 1, 0, (hipStream_t)stream>>>((SamplerBuf*)d_buf);
+  HIP_TRY(hipGetLastError());
   return ANEMOI_OK;
 }
 

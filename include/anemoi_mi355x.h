@@ -128,15 +128,19 @@ int anemoi_probe_issue_rate(int device, double *lane_mad_per_s, double *shader_c
  * shader-cycle counter) every period_us; the caller brackets its work with two wall-clock stamps on ITS stream, stops the
  * sampler and reads the mean / min / max clock (GHz, over the sampler's workgroups) between the stamps:
  *     buf = device memory of anemoi_clock_sampler_bytes(), 8-byte aligned; stamps = two device uint64
- *     anemoi_clock_sampler_start_dev(buf, bytes, 2000, 60000, side_stream);   anemoi_clock_stamp_dev(&stamps[0], work_stream);
+ *     anemoi_clock_sampler_start_dev(buf, bytes, 2000, 60000, side_stream);   anemoi_clock_sampler_wait_dev(buf, 50, work_stream);
+ *                                                                              anemoi_clock_stamp_dev(&stamps[0], work_stream);
  *     ... the work, on work_stream ...                                         anemoi_clock_stamp_dev(&stamps[1], work_stream);
  *     anemoi_clock_sampler_stop_dev(buf, third_stream);   synchronise;   copy buf and stamps to the host;
  *     anemoi_clock_sampler_read(host_buf, bytes, stamps[0], stamps[1], &mean, &lo, &hi, &groups);
  * (period_us 10 ... 1 000 000, max_ms 1 ... 600 000, else ANEMOI_ERR_ARG.)
  * The sampler ends when stopped, when its log (4 096 samples) is full, or after max_ms, whichever comes first.  The stop
- * must be issued on a stream that does not wait for the sampler.  bench.py reports the clock of its timed steps this way. */
+ * must be issued on a stream that does not wait for the sampler.  anemoi_clock_sampler_wait_dev holds `stream` (a one-lane
+ * kernel, at most timeout_ms = 1 ... 10 000) until the sampler has taken its first sample: a sampler whose stream is slow
+ * to start would otherwise miss a short piece of work.  bench.py reports the clock of its timed steps this way. */
 size_t anemoi_clock_sampler_bytes(void);
 int anemoi_clock_sampler_start_dev(void *d_buf, size_t bytes, unsigned period_us, unsigned max_ms, void *stream);
+int anemoi_clock_sampler_wait_dev(void *d_buf, unsigned timeout_ms, void *stream);
 int anemoi_clock_sampler_stop_dev(void *d_buf, void *stream);
 int anemoi_clock_stamp_dev(void *d_u64, void *stream);
 int anemoi_clock_sampler_read(const void *h_buf, size_t bytes, unsigned long long t0, unsigned long long t1, double *ghz_mean,

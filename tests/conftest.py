@@ -17,6 +17,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """ANEMOI_TEST_ORDER=reverse | shuffle:<seed> runs the collected tests in another order (tests must not depend on what
+    ran before them: constant tables, lanes and code objects are loaded on first use by whichever test comes first)."""
+    order = os.environ.get("ANEMOI_TEST_ORDER", "")
+    if order == "reverse":
+        items.reverse()
+    elif order.startswith("shuffle:"):
+        import random
+        random.Random(int(order.split(":", 1)[1])).shuffle(items)
+
+
 class knobs:
     """Library options for the duration of a with-block, through anemoi_set_option (options are read from the
     environment once and changed only through the API; names are option names or their ANEMOI_* variables).

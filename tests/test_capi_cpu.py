@@ -75,6 +75,8 @@ def test_argument_errors_need_no_device(A):
         assert L.anemoi_clock_sampler_start_dev(big.ctypes.data, big.nbytes, period_us, max_ms, None) == -3
     assert L.anemoi_clock_sampler_start_dev(big.ctypes.data + 4, big.nbytes - 4, 2000, 1000, None) == -3   # misaligned
     assert L.anemoi_clock_sampler_stop_dev(None, None) == -3
+    assert L.anemoi_clock_sampler_wait_dev(None, 50, None) == -3
+    assert L.anemoi_clock_sampler_wait_dev(big.ctypes.data, 0, None) == -3 and L.anemoi_clock_sampler_wait_dev(big.ctypes.data, 10001, None) == -3
     assert L.anemoi_clock_stamp_dev(None, None) == -3
     assert L.anemoi_clock_stamp_dev(buf.ctypes.data + 4, None) == -3
     assert L.anemoi_ragged_scratch_bytes(1000) == (65536 + 1000) * 4
