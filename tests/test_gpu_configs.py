@@ -567,26 +567,28 @@ def test_dev_jive_rejects_overlapping_buffers(A):
 
 
 def test_concurrent_callers_overlap_on_the_gpu(A, oracle):
-    """Every host-pointer call runs on its own lane (own non-blocking streams), so latency-bound calls
-    from several threads overlap on the device: 4 threads x 6 single-wave batches must take well under the
-    serial time (a NULL-stream / hipMalloc-per-call implementation serialises them)."""
+    """Every host-pointer call runs on its own lane (own non-blocking streams), so latency-bound calls from several
+    threads overlap on the device: 4 threads x 3 Merkle roots of depth 8 (eight dependent launches of at most 64
+    wavefronts each: ~14 ms of pure kernel latency per call, next to which the host's share -- and the interpreter
+    lock the threads take turns on -- is small) must take well under the serial time; a NULL-stream or
+    hipMalloc-per-call implementation serialises them (ratio 1.0), perfect overlap is 0.25."""
     fid = FIELD_IDS.index("bls12_381")
     rng = np.random.default_rng(9)
-    sts = [rng.integers(0, 1 << 60, size=(48, 2, 6), dtype=np.uint64) for _ in range(4)]
-    want = [oracle.compress_batch(fid, 2, s, threads=4) for s in sts]
+    depth, reps = 8, 3
+    lvs = [rng.integers(0, 1 << 60, size=(1 << depth, 6), dtype=np.uint64) for _ in range(4)]
+    want = [oracle.merkle_root(fid, l, depth) for l in lvs]
     inst = A.Anemoi("bls12_381", 2)
-    for s in sts:
-        inst.compress_batch(s)  # warm: lanes, constants
-    reps = 6
+    for l in lvs:
+        inst.merkle_root(l, depth)  # warm: lanes, constants
 
     def run(k, errs):
         for _ in range(reps):
-            if not (inst.compress_batch(sts[k]) == want[k]).all():
+            if not (inst.merkle_root(lvs[k], depth) == want[k]).all():
                 errs.append(k)
 
     errs, ratios = [], []
-    for attempt in range(3):      # a timing assertion: the best of three attempts (typical 0.5-0.6; a serialising
-        t0 = time.perf_counter()  # implementation sits at 1.0 whatever the box is doing besides)
+    for attempt in range(3):      # a timing assertion: the best of three attempts (typical 0.3-0.4)
+        t0 = time.perf_counter()
         for k in range(4):
             run(k, errs)
         serial = time.perf_counter() - t0
@@ -599,7 +601,7 @@ def test_concurrent_callers_overlap_on_the_gpu(A, oracle):
         conc = time.perf_counter() - t0
         print("4 x %d latency-bound calls: serial %.1f ms, concurrent %.1f ms" % (reps, serial * 1e3, conc * 1e3))
         ratios.append(conc / serial)
-        if ratios[-1] < 0.6:
+        if ratios[-1] < 0.5:
             break
     assert not errs
     assert min(ratios) < 0.7, ratios
