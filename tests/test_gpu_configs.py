@@ -604,7 +604,9 @@ def test_concurrent_callers_overlap_on_the_gpu(A, oracle):
         if ratios[-1] < 0.5:
             break
     assert not errs
-    assert min(ratios) < 0.7, ratios
+    # (0.38 with GPU_MAX_HW_QUEUES=8, 0.52-0.59 with HIP's default of 4 queues shared by all streams of the process --
+    #  profiles/r05/concurrent_callers_hw_queues.txt; an unlucky stream-to-queue assignment costs more, serialisation gives 1.0)
+    assert min(ratios) < 0.85, ratios
 
 
 # ---------------------------------------------------------------- bench.py --gpus 2: the driver's N > 1 launch line
