@@ -194,7 +194,8 @@ def test_mixed_entry_points_from_many_threads_while_the_cut_offs_change(A, oracl
     """Seven host threads, each hammering a different host-pointer entry point (small and chunked Jive batches, both
     sponges, both ragged forms, a Merkle root, a permutation) on different fields, while an eighth flips the
     kernel-selection cut-offs back and forth: every call must return what the same call returned single-threaded
-    (the options choose kernels, never results; lanes, pools and constant tables are shared state).  One result of each
+    (the options choose kernels, never results; lanes, pools and constant tables are shared state -- and are rebuilt by
+    the threads' first calls, all at once, after an anemoi_release).  One result of each
     kind is also checked against the oracle."""
     import threading
     import time
@@ -239,6 +240,7 @@ def test_mixed_entry_points_from_many_threads_while_the_cut_offs_change(A, oracl
         for k in keys:
             A.set_option(k, saved[k])
 
+    A.release(0)        # everything the library holds is gone: the threads' FIRST calls rebuild lanes and constant tables concurrently
     fl = threading.Thread(target=flipper)
     fl.start()
     ths = [threading.Thread(target=worker, args=(k,)) for k in jobs]
