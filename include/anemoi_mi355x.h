@@ -98,7 +98,8 @@ int anemoi_num_rounds(int field, int width); /* NUM_HASH_ROUNDS, src/<f>/anemoi_
  * neither allocate nor synchronise.  anemoi_release frees everything the library holds on `device`
  * (constant tables, idle lanes with their streams and buffers); ANEMOI_ERR_ARG while host-pointer calls are in
  * flight there.  `_dev` work the caller has enqueued on its own streams is the caller's to wait for first: its
- * kernels read the constant tables.  The library can be used again afterwards (it re-initialises lazily). */
+ * kernels read the constant tables -- and a hipGraph captured from `_dev` calls holds the tables' addresses: capture again
+ * after a release, do not replay.  The library can be used again afterwards (it re-initialises lazily). */
 int anemoi_init(int device, int field, int width);
 int anemoi_release(int device);
 /* anemoi_init, then ONE small launch (16 x SIMDs items of zeros, a few ms) of every throughput kernel of (field, width):
