@@ -11,11 +11,11 @@ form (the arkworks in-memory form, see the header).  `to_montgomery` / `from_mon
 canonical integers on the GPU.
 """
 from . import synth  # noqa: F401  (seeded workloads of the BASELINE configs)
-from ._lib import (ALL_DEVICES, FIELD_IDS, Anemoi, AnemoiError, GenericAnemoi, builtin_mds_matrix, exp_alpha_batch, device_count, field_id, init, lib, lib_path, release, warmup, probe_issue_rate, ClockSampler,
+from ._lib import (ALL_DEVICES, FIELD_IDS, Anemoi, AnemoiError, GenericAnemoi, builtin_mds_matrix, exp_alpha_batch, device_count, field_id, init, lib, lib_path, release, warmup, probe_issue_rate, ClockSampler, kernel_Mcycles,
                    AUTO, OPTIONS, options, set_option, get_option, is_ab_build,
                    from_montgomery, to_montgomery, ints_to_limbs, limbs_to_ints)
 
 __all__ = ["ALL_DEVICES", "FIELD_IDS", "Anemoi", "AnemoiError", "GenericAnemoi", "builtin_mds_matrix",
-           "exp_alpha_batch", "device_count", "field_id", "init", "lib", "lib_path", "release", "warmup", "probe_issue_rate", "ClockSampler", "synth",
+           "exp_alpha_batch", "device_count", "field_id", "init", "lib", "lib_path", "release", "warmup", "probe_issue_rate", "ClockSampler", "kernel_Mcycles", "synth",
            "from_montgomery", "to_montgomery", "ints_to_limbs", "limbs_to_ints", "AUTO", "OPTIONS", "options", "is_ab_build",
            "set_option", "get_option"]

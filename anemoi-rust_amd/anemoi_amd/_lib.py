@@ -211,6 +211,35 @@ class ClockSampler:
         return v[0].value, v[1].value, v[2].value, g.value
 
 
+def kernel_Mcycles(device, enqueue, reps=3, warmup=1, best=False):
+    """The box-independent cost of a piece of device work: `enqueue(stream)` (one or more `_dev` calls) run `reps` times with
+    the clock sampler beside it.  Returns (ms per repetition from HIP events on the work's stream, the SLOWEST sampled XCD
+    clock in GHz, their product in millions of shader cycles) -- bench.py's `alu.kernel_Mcycles_slowest_xcd` for any
+    kernel: a slower box moves the clock, a slower build moves the cycles.  best: the fastest
+    repetition instead of the mean (a budget test: one repetition that met a launch-order effect must not fail a build)."""
+    import torch
+    stream = torch.cuda.current_stream(device)
+    for _ in range(warmup):
+        enqueue(stream)
+    torch.cuda.synchronize(device)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    cs = ClockSampler(device)
+    cs.start(stream)
+    for a, b in evs:
+        a.record(stream)
+        enqueue(stream)
+        b.record(stream)
+    cs.finish(stream)
+    torch.cuda.synchronize(device)
+    _, ghz_min, _, groups = cs.read()
+    if not groups or ghz_min <= 0:
+        raise RuntimeError("the clock sampler took no sample beside the work")
+    each = [a.elapsed_time(b) for a, b in evs]
+    ms = min(each) if best else sum(each) / reps
+    kernel_Mcycles.last_each_ms = each
+    return ms, ghz_min, ms * ghz_min
+
+
 def release(device=ALL_DEVICES):
     """Free everything the library holds on `device` (anemoi_release); it re-initialises lazily afterwards."""
     rc = lib.anemoi_release(device)

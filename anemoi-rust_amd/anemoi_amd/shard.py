@@ -30,3 +30,51 @@ def max_over_ranks(value, dist=None, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class ControlPlaneAudit:
+    """Counts what crosses torch.distributed while it is installed: every tensor-carrying collective / point-to-point
+    function of the module is wrapped, so that bench.py's line can state -- and a test can assert -- that nothing but
+    8-byte scalars (the max-over-ranks of the elapsed time, the failure flag, the probe's minimum) and barriers ever
+    crossed the control plane: there is no collective on the data path."""
+
+    TENSOR_CALLS = ("all_reduce", "broadcast", "reduce", "all_gather", "all_gather_into_tensor", "gather", "scatter",
+                    "reduce_scatter", "reduce_scatter_tensor", "all_to_all", "all_to_all_single", "send", "recv",
+                    "isend", "irecv", "all_gather_object", "broadcast_object_list", "gather_object", "scatter_object_list")
+
+    def __init__(self, dist):
+        self.dist, self.calls, self.max_tensor_bytes, self._saved = dist, {}, 0, {}
+
+    def _note(self, name, args, kwargs):
+        import torch
+        self.calls[name] = self.calls.get(name, 0) + 1
+        if "object" in name:
+            self.max_tensor_bytes = max(self.max_tensor_bytes, 1 << 62)   # pickled objects: never on this control plane
+        stack = list(args) + list(kwargs.values())
+        while stack:
+            a = stack.pop()
+            if isinstance(a, torch.Tensor):
+                self.max_tensor_bytes = max(self.max_tensor_bytes, a.numel() * a.element_size())
+            elif isinstance(a, (list, tuple)):
+                stack.extend(a)
+
+    def install(self):
+        for name in self.TENSOR_CALLS + ("barrier",):
+            fn = getattr(self.dist, name, None)
+            if fn is None:
+                continue
+            self._saved[name] = fn
+
+            def wrapped(*args, _fn=fn, _name=name, **kwargs):
+                self._note(_name, args, kwargs)
+                return _fn(*args, **kwargs)
+            setattr(self.dist, name, wrapped)
+        return self
+
+    def remove(self):
+        for name, fn in self._saved.items():
+            setattr(self.dist, name, fn)
+        self._saved = {}
+
+    def report(self):
+        return {"calls": dict(sorted(self.calls.items())), "max_tensor_bytes": self.max_tensor_bytes}

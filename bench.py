@@ -13,6 +13,10 @@ synthetic states that are already resident in HBM.
          (RCCL) carries only the barrier and the max-over-ranks of the elapsed time.  Per-GPU work is
          fixed for every N > 1 ("weak" scaling); N = 1 runs half of that (config 2), at the same rate.
 `value` = all ranks' items / max-over-ranks time.
+  ANEMOI_BENCH_FORCE_DIST=1 makes a WORLD_SIZE = 1 launch (`torch.distributed.run --nproc-per-node 1`) take the N > 1
+  code path: the RCCL process group with `device_id`, the communicator-creating barrier, the max-over-ranks on a device
+  tensor, the all-ranks failure flag, shard 0 of config 4 -- so that the control plane of the first real scaling run has
+  executed on the one-GPU boxes the builder gets (RCCL refuses two ranks on one device; it accepts one).
 
 The line proves itself: after the timed loop every rank compares the outputs still sitting in its output
 buffer with the committed oracle goldens of that exact batch (tests/golden/cfg_full.json, minted by
@@ -133,12 +137,13 @@ def cpu_baseline(synth, budget_s=10.0):
             "reference_binary": reference_toolchain_probe()}
 
 
-def rank_shard(rank, world, batch_log2=None):
+def rank_shard(rank, world, batch_log2=None, sharded=None):
     """(config name, config, first item, item count) of `rank` out of `world`: config 2 alone on one GPU,
-    contiguous 2^21-item shards of config 4 otherwise."""
+    contiguous 2^21-item shards of config 4 otherwise (`sharded`: world > 1, or forced by ANEMOI_BENCH_FORCE_DIST)."""
     from anemoi_amd import synth
-    cfg_name, cfg = ("cfg2", synth.CFG2) if world == 1 else ("cfg4", synth.CFG4)
-    lg = batch_log2 if batch_log2 is not None else (20 if world == 1 else 21)
+    sharded = (world > 1) if sharded is None else sharded
+    cfg_name, cfg = ("cfg4", synth.CFG4) if sharded else ("cfg2", synth.CFG2)
+    lg = batch_log2 if batch_log2 is not None else (21 if sharded else 20)
     n = 1 << lg
     first = rank * n
     if first + n > cfg["n"]:
@@ -198,10 +203,15 @@ def main():
     ndev = torch.cuda.device_count()
     local_rank = local_rank % max(ndev, 1) if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
+    dist, audit = None, None
+    # the N > 1 code path at WORLD_SIZE = 1 (see the module docstring): one rank is all RCCL accepts on a one-GPU box
+    distributed = world > 1 or os.environ.get("ANEMOI_BENCH_FORCE_DIST") == "1"
+    if distributed:
         import torch.distributed as dist
+        from anemoi_amd.shard import ControlPlaneAudit
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        audit = ControlPlaneAudit(dist).install()          # every tensor that crosses torch.distributed is counted
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             dist.barrier()  # create the RCCL communicator now, outside the timed region
@@ -212,7 +222,7 @@ def main():
     from anemoi_amd import buildinfo, synth
     from anemoi_amd.shard import max_over_ranks
     fid = A.field_id(FIELD)
-    cfg_name, cfg, first, n = rank_shard(rank, world, args.batch_log2)   # contiguous shards of the config's batch
+    cfg_name, cfg, first, n = rank_shard(rank, world, args.batch_log2, distributed)   # contiguous shards of the config's batch
     lg = n.bit_length() - 1
     dev = torch.device("cuda", local_rank)
     host = synth.states(FIELD, WIDTH, cfg["seed"], first, n)
@@ -316,12 +326,15 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": ("BASELINE config 2: Anemoi-2-1 over BLS12-381 basefield, 2^%d batched Jive compressions "
-                                    "on one GPU, inputs resident in HBM" % lg) if world == 1 else
+                                    "on one GPU, inputs resident in HBM" % lg) if not distributed else
                                    ("BASELINE config 4: Anemoi-2-1 over BLS12-381, 2^24-state batch in 8 contiguous shards, "
                                     "rank r runs shard r (2^%d items per GPU, %d of 8 shards), no collective on the data path"
                                     % (lg, world)),
                        "field": FIELD, "state_width": WIDTH, "batch_per_gpu": n, "parallelism": "shard%d" % world,
-                       "seed": cfg["seed"], "control_plane": (backend if world > 1 else "none")},
+                       "seed": cfg["seed"], "control_plane": (backend if distributed else "none"),
+                       # everything that crossed torch.distributed in this run, counted by a wrapper around the module's
+                       # collectives (anemoi_amd/shard.py: ControlPlaneAudit): barriers and 8-byte scalars, nothing else
+                       "control_plane_traffic": (audit.report() if audit else None)},
             "verified": {"against": "tests/golden/cfg_full.json:%s (CPU oracle)" % cfg_name, "items_compared": checked,
                          "sha256_of_all_outputs": sha_ok, "ranks": world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -377,7 +390,7 @@ def main():
                             "1024 SIMDs x 16 lanes per clock at 2.4 GHz; the path is VALU-bound, see DESIGN.md"
                             % (sq_r, lay["sqr_mad"], mu_r, lay["mul_mad"], lay["mul_mad"])},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(synth)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -117,3 +117,38 @@ def test_single_gpu_shard_is_config2():
     assert (name, first, n, cfg["seed"]) == ("cfg2", 0, 1 << 20, 0xA9E30102)
     name, cfg, first, n = bench.rank_shard(7, 8)
     assert (name, first, n, first + n) == ("cfg4", 7 << 21, 1 << 21, 1 << 24)
+    # ANEMOI_BENCH_FORCE_DIST=1: one rank takes the N > 1 path = shard 0 of config 4
+    name, cfg, first, n = bench.rank_shard(0, 1, sharded=True)
+    assert (name, first, n, cfg["seed"]) == ("cfg4", 0, 1 << 21, 0xA9E30104)
+
+
+def audit_worker(rank, world, port, out_path):
+    sys.path.insert(0, os.path.join(ROOT, "anemoi-rust_amd"))
+    os.environ["ANEMOI_NO_TORCH_PRELOAD"] = "1"
+    import torch
+    from anemoi_amd.shard import ControlPlaneAudit, max_over_ranks
+    audit = ControlPlaneAudit(dist).install()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dist.barrier()
+    assert max_over_ranks(float(rank), dist) == world - 1
+    clean = audit.report()
+    dist.all_reduce(torch.zeros(1024, dtype=torch.float32))          # what a data-path collective would look like
+    big = audit.report()
+    audit.remove()
+    dist.all_reduce(torch.zeros(4096, dtype=torch.float32))          # no longer counted
+    after = audit.report()
+    if rank == 0:
+        json.dump([clean, big, after], open(out_path, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_control_plane_audit_counts_every_tensor(tmp_path):
+    """bench.py's line states what crossed torch.distributed (config.control_plane_traffic); the wrapper that counts it sees
+    the barrier, the 8-byte scalar of max_over_ranks, and -- were one ever added -- a data-path collective."""
+    out = str(tmp_path / "audit.json")
+    mp.spawn(audit_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    clean, big, after = json.load(open(out))
+    assert clean == {"calls": {"all_reduce": 1, "barrier": 1}, "max_tensor_bytes": 8}
+    assert big == {"calls": {"all_reduce": 2, "barrier": 1}, "max_tensor_bytes": 4096}
+    assert after == big

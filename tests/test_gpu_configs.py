@@ -624,6 +624,7 @@ def _bench_two_ranks(extra_env, ranks=2):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("ANEMOI_BENCH_BACKEND", None)
     env.pop("ANEMOI_BENCH_TEST_CORRUPT_RANK", None)
+    env.pop("ANEMOI_BENCH_FORCE_DIST", None)
     env.update(extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1"]
@@ -678,3 +679,29 @@ def test_bench_two_ranks_over_rccl(A):
     assert line["n_gpus"] == 2 and line["verified"]["ranks"] == 2 and line["verified"]["sha256_of_all_outputs"] is True
     assert line["config"]["control_plane"] == "nccl" and line["config"]["parallelism"] == "shard2"
     assert line["scaling"] == "weak" and line["value"] > 0
+
+
+# ---------------------------------------------------------------- bench.py's RCCL branch with the ONE rank RCCL accepts on a one-GPU box
+
+def test_bench_one_rank_over_rccl(A):
+    """RCCL refuses two ranks on one device, so the branch the driver's first scaling run takes -- init_process_group("nccl",
+    device_id=...), the communicator-creating barrier, max_over_ranks on a DEVICE tensor, the all-ranks failure flag,
+    destroy_process_group -- is run here with ONE rank: `torch.distributed.run --nproc-per-node 1` with
+    ANEMOI_BENCH_FORCE_DIST=1 (the N > 1 code path at WORLD_SIZE = 1: shard 0 of config 4, verified against its goldens),
+    as a child process.  Then the same launch with the rank's output corrupted: no line, non-zero exit, the process group
+    torn down.  The line states what crossed torch.distributed: barriers and 8-byte scalars -- there is NO collective on
+    the data path (north_star).  This is not an N > 1 measurement: none exists."""
+    p = _bench_two_ranks({"ANEMOI_BENCH_FORCE_DIST": "1"}, ranks=1)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["control_plane"] == "nccl" and line["n_gpus"] == 1
+    assert line["config"]["batch_per_gpu"] == 1 << 21 and "config 4" in line["config"]["workload"]
+    assert line["verified"]["sha256_of_all_outputs"] is True and line["verified"]["items_compared"] == 512
+    traffic = line["config"]["control_plane_traffic"]
+    assert traffic["max_tensor_bytes"] == 8, traffic                      # nothing larger than one double ever crossed RCCL
+    assert set(traffic["calls"]) == {"all_reduce", "barrier"}, traffic    # time, probe minimum, failure flag; barriers
+    assert traffic["calls"]["all_reduce"] == 3 and traffic["calls"]["barrier"] >= 3, traffic
+    assert "cpu_baseline" not in line and line["value"] > 0
+    bad = _bench_two_ranks({"ANEMOI_BENCH_FORCE_DIST": "1", "ANEMOI_BENCH_TEST_CORRUPT_RANK": "0"}, ranks=1)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+    assert "rank 0" in bad.stderr

@@ -13,8 +13,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import torch
+# the summariser picks a config's dispatch by its grid and prices its bytes from these
+from summarize_config_profiles import CFG3_MESSAGES, CFG3_MSG_LEN, WARM_MESSAGES, WARM_MSG_LEN
 
 
 def main():
@@ -41,8 +44,8 @@ def main():
                 assert lib.anemoi_jive_compress_k_dev(field, width, 2, d_in.data_ptr(), d_out.data_ptr(), n, s) == 0
             torch.cuda.synchronize()
     if "cfg3" in want:
-        nmsg = 1 << 16
-        msgs = torch.from_numpy(rng.integers(0, 256, size=(nmsg, 10240), dtype=np.uint8)).to(dev)
+        nmsg = CFG3_MESSAGES
+        msgs = torch.from_numpy(rng.integers(0, 256, size=(nmsg, CFG3_MSG_LEN), dtype=np.uint8)).to(dev)
         dig = torch.empty(nmsg * 4, dtype=torch.int64, device=dev)
         # The FIRST launch of this kernel in a process takes 487-491 ms of kernel time instead of 333 (rocprofv3 trace;
         # tools/exp_cfg3_repeat.py, profiles/r04/first_launch_after_idle.txt).  Other kernels launched before do not change
@@ -51,9 +54,9 @@ def main():
         # it looks like the first dispatch of a kernel placing its workgroups on part of the chip; the cause is not
         # established.  Two small launches first, so that the timed ones measure the steady state.
         for _ in range(2):
-            assert lib.anemoi_hash_bytes_dev(2, 4, msgs.data_ptr(), 93, 1 << 15, dig.data_ptr(), s) == 0
+            assert lib.anemoi_hash_bytes_dev(2, 4, msgs.data_ptr(), WARM_MSG_LEN, WARM_MESSAGES, dig.data_ptr(), s) == 0
         for _ in range(reps):
-            assert lib.anemoi_hash_bytes_dev(2, 4, msgs.data_ptr(), 10240, nmsg, dig.data_ptr(), s) == 0
+            assert lib.anemoi_hash_bytes_dev(2, 4, msgs.data_ptr(), CFG3_MSG_LEN, nmsg, dig.data_ptr(), s) == 0
         torch.cuda.synchronize()
     if "cfg5" in want:
         depth = 21

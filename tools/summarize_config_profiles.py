@@ -11,6 +11,13 @@
     2^20 Jubjub 2-1 compressions).
 
     python tools/summarize_config_profiles.py gpurun_out/prof_cfg_<tag>
+    python tools/summarize_config_profiles.py --resummarize profiles/rNN/pmc_configs.json    # summary + derived bytes again
+                                                                                             # from the file's kernel rows
+
+A config's dispatch is picked BY ITS GRID (tools/profile_workloads.py also launches the same kernels on small batches
+as its own warm-up: rounds 3-5 summarised that launch as config 3 -- 1.9 ms, "166 x the flat rate"), every row's
+algorithmic bytes come from ITS grid and message length, and a summary whose fractions are not fractions is an error,
+not an output (`check_summary`; tests/test_docs_cpu.py re-derives the newest committed summary from its rows).
 """
 import csv
 import glob
@@ -20,6 +27,14 @@ import re
 import sys
 
 CUS, SIMDS, XCDS = 256, 4, 8
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+# the sponge launches of tools/profile_workloads.py: (kernel, grid) -> (messages, bytes per message).  k_sponge_pair puts
+# a message on a lane pair: grid = 2 x messages work-items.
+CFG3_MESSAGES, CFG3_MSG_LEN, CFG3_PERMS = 1 << 16, 10240, 111
+WARM_MESSAGES, WARM_MSG_LEN = 1 << 15, 93
+SPONGE_LAUNCHES = {("k_sponge_pair<2, true>", 2 * CFG3_MESSAGES): (CFG3_MESSAGES, CFG3_MSG_LEN),
+                   ("k_sponge_pair<2, true>", 2 * WARM_MESSAGES): (WARM_MESSAGES, WARM_MSG_LEN)}
 
 
 def find(d, pat):
@@ -66,9 +81,12 @@ def items_per_wave(kernel):
     return 32 if ("_pair" in kernel) else 64
 
 
-def algorithmic_bytes(kernel, items):
-    if kernel.startswith("k_sponge_pair<2"):
-        return 10272 * items           # config 3: 10 240 message bytes + a 32-byte digest
+def algorithmic_bytes(kernel, items, grid=None):
+    if kernel.startswith("k_sponge"):
+        if (kernel, grid) not in SPONGE_LAUNCHES:
+            return None                # a sponge launch this tool does not know the message length of: no figure, not a guess
+        messages, msg_len = SPONGE_LAUNCHES[(kernel, grid)]
+        return (msg_len + 32) * messages   # config 3: 10 240 message bytes + a 32-byte digest = 10 272 B per message
     if kernel.startswith("k_jive<4") or kernel.startswith("k_jive2_coop<4"):
         return 96 * items              # Jubjub merge: 64 B in + 32 B out (the cooperative kernel's partly filled last wavefront counted whole)
     if kernel.startswith("k_jive_pair<2"):
@@ -117,12 +135,39 @@ def main():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             rec["hbm_traffic_bytes"] = 2 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024
             if items:
-                ab = algorithmic_bytes(k, items if "sponge" not in k else int(round(waves * ipw)))
+                ab = algorithmic_bytes(k, items, grid)
                 if ab:
                     rec["algorithmic_bytes"] = ab
                     rec["traffic_over_algorithmic"] = rec["hbm_traffic_bytes"] / ab
         recs.append(rec)
+    out = {"summary": check_summary(summarize(recs), recs), "kernels": recs,
+           "note": "rocprofv3 passes of `python3 tools/profile_workloads.py cfg3 cfg5 flat --reps 2` "
+                   "(tools/collect_config_profiles.sh): --kernel-trace --stats for the times, separate --pmc passes for "
+                   "FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set; counters and times are those of the FASTEST dispatch of a (kernel, "
+                   "grid) pair in each pass (the first dispatch of a workload pays first-touch effects), summed over a counter's hardware instances; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled "
+                   "(gfx950 reports half of a wide coalesced read); GRBM_GUI_ACTIVE summed over the 8 XCDs; "
+                   "SQ_WAVE_CYCLES in quad-cycles.  A config's dispatch is selected by its grid (config 3: 2^16 messages on lane "
+                   "pairs = grid 131 072; the grid-65 536 row of the same kernel is the profiling tool's own small launch)."}
+    with open(os.path.join(d, "pmc_configs.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out["summary"], indent=1)[:3000])
 
+
+def rederive_bytes(recs):
+    """algorithmic_bytes / traffic_over_algorithmic of every row again from its grid (for files written before round 6)"""
+    for r in recs:
+        r.pop("algorithmic_bytes", None)
+        r.pop("traffic_over_algorithmic", None)
+        items = int(round(r["wavefronts"] * items_per_wave(r["kernel"])))
+        ab = algorithmic_bytes(r["kernel"], items, r["grid"]) if "hbm_traffic_bytes" in r and items else None
+        if ab:
+            r["algorithmic_bytes"] = ab
+            r["traffic_over_algorithmic"] = r["hbm_traffic_bytes"] / ab
+    return recs
+
+
+def summarize(recs):
+    """the summary object from the per-(kernel, grid) rows alone"""
     def med(kernel, pred=lambda g: True):
         xs = [r for r in recs if r["kernel"] == kernel and pred(r["grid"]) and r["kernel_ms_min_stats_pass"]]
         return xs[0] if xs else None
@@ -133,9 +178,9 @@ def main():
         summary["flat_jubjub_2_1_M_per_s"] = (1 << 20) / flat_j["kernel_ms_min_stats_pass"] / 1e3
     if flat_b:
         summary["flat_bn254_4_3_M_per_s"] = (1 << 20) / flat_b["kernel_ms_min_stats_pass"] / 1e3
-    sp = med("k_sponge_pair<2, true>")
+    sp = med("k_sponge_pair<2, true>", lambda g: g == 2 * CFG3_MESSAGES)        # config 3's dispatch, not the tool's small one
     if sp and flat_b:
-        perm_rate = (1 << 16) * 111 / sp["kernel_ms_min_stats_pass"] / 1e3      # M permutations / s
+        perm_rate = CFG3_MESSAGES * CFG3_PERMS / sp["kernel_ms_min_stats_pass"] / 1e3      # M permutations / s
         summary["cfg3_ms"] = sp["kernel_ms_min_stats_pass"]
         summary["cfg3_fraction_of_flat_rate"] = perm_rate / summary["flat_bn254_4_3_M_per_s"]
     if flat_j:
@@ -160,17 +205,40 @@ def main():
         summary["cfg5_sum_of_levels_ms"] = tree_ms
         if tree_ms:
             summary["cfg5_fraction_of_flat_rate"] = ((1 << 21) - 1) / tree_ms / 1e3 / summary["flat_jubjub_2_1_M_per_s"]
-    out = {"summary": summary, "kernels": recs,
-           "note": "rocprofv3 passes of `python3 tools/profile_workloads.py cfg3 cfg5 flat --reps 2` "
-                   "(tools/collect_config_profiles.sh): --kernel-trace --stats for the times, separate --pmc passes for "
-                   "FETCH_SIZE, WRITE_SIZE and the SQ/GRBM set; counters and times are those of the FASTEST dispatch of a (kernel, "
-                   "grid) pair in each pass (the first dispatch of a workload pays first-touch effects), summed over a counter's hardware instances; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled "
-                   "(gfx950 reports half of a wide coalesced read); GRBM_GUI_ACTIVE summed over the 8 XCDs; "
-                   "SQ_WAVE_CYCLES in quad-cycles."}
-    with open(os.path.join(d, "pmc_configs.json"), "w") as f:
-        json.dump(out, f, indent=1)
-    print(json.dumps(summary, indent=1)[:3000])
+    return summary
+
+
+def check_summary(summary, recs=None):
+    """A fraction of the flat rate is a fraction; HBM traffic is at least what the algorithm moves.  Raises on anything else."""
+    for key in ("cfg3_fraction_of_flat_rate", "cfg5_fraction_of_flat_rate"):
+        if key in summary and not 0.3 < summary[key] <= 1.02:
+            raise SystemExit("summarize_config_profiles: %s = %r is not a fraction of the flat rate -- wrong dispatch selected?"
+                             % (key, summary[key]))
+    if "cfg3_ms" in summary and not 100.0 < summary["cfg3_ms"] < 2000.0:
+        raise SystemExit("summarize_config_profiles: cfg3_ms = %r cannot be 2^16 messages x 111 permutations" % summary["cfg3_ms"])
+    for r in recs or []:
+        t = r.get("traffic_over_algorithmic")
+        if t is not None and not 0.95 < t < 1000.0:
+            raise SystemExit("summarize_config_profiles: %s grid %d: traffic / algorithmic = %r" % (r["kernel"], r["grid"], t))
+    return summary
+
+
+def resummarize(path):
+    doc = json.load(open(path))
+    before = doc["summary"]
+    recs = rederive_bytes(doc["kernels"])
+    doc["summary"] = check_summary(summarize(recs), recs)
+    if before != doc["summary"] and "resummarized" not in doc["note"]:
+        doc["note"] += ("  [resummarized: `summary`, `algorithmic_bytes` and `traffic_over_algorithmic` re-derived from the kernel rows by "
+                        "tools/summarize_config_profiles.py --resummarize; the summary written at collection time had taken the "
+                        "profiling tool's own small launch of k_sponge_pair<2, true> (grid 65 536) for config 3's (grid 131 072).]")
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1)
+    print(json.dumps({k: v for k, v in doc["summary"].items() if k != "cfg5_levels"}, indent=1))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--resummarize":
+        resummarize(sys.argv[2])
+    else:
+        main()
