@@ -89,9 +89,9 @@ _SIGS = {
     "anemoi_hash_field_ragged_batch": ([_int, _int, _u64p, _u64p, _sz, _u64p, _int], _int),
     "anemoi_hash_bytes_ragged_dev": ([_int, _int, _vp, _vp, _sz, _vp, _vp], _int),
     "anemoi_ragged_scratch_bytes": ([_sz], _sz),
-    "anemoi_hash_bytes_ragged_bucketed_dev": ([_int, _int, _vp, _vp, _sz, _vp, _vp, _sz, _vp], _int),
+    "anemoi_hash_bytes_ragged_bucketed_dev": ([_int, _int, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp], _int),
     "anemoi_hash_field_ragged_dev": ([_int, _int, _vp, _vp, _sz, _vp, _vp], _int),
-    "anemoi_hash_field_ragged_bucketed_dev": ([_int, _int, _vp, _vp, _sz, _vp, _vp, _sz, _vp], _int),
+    "anemoi_hash_field_ragged_bucketed_dev": ([_int, _int, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp], _int),
     "anemoi_merkle_root": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
     "anemoi_merkle_tree": ([_int, _u64p, ctypes.c_uint, _u64p, _int], _int),
     "anemoi_merkle_path": ([_int, _u64p, ctypes.c_uint, _sz, _u64p], _int),

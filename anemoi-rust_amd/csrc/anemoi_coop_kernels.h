@@ -480,7 +480,8 @@ __global__ __launch_bounds__(kBlock) void k_sponge_coop(const void* __restrict__
 template <int FIELD, int W, bool BYTES, int LPR = 16>
 __global__ __launch_bounds__(kBlock) void k_sponge_ragged_coop(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off,
                                                                size_t n, uint32_t* __restrict__ out, PermConsts pc,
-                                                               const uint32_t* __restrict__ order) {
+                                                               const uint32_t* __restrict__ order,
+                                                               const uint32_t* __restrict__ status) {
   using F = FieldC<FIELD>;
   using C = typename CoopArith<F, LPR>::type;
   static_assert(LPR <= 32, "two or four rows per wavefront");
@@ -495,14 +496,18 @@ __global__ __launch_bounds__(kBlock) void k_sponge_ragged_coop(const uint8_t* __
     const bool live = want < n;
     const size_t slot = live ? want : n - 1;
     const size_t item = order ? size_t(order[slot]) : slot;
-    const uint64_t o0 = off[item], len = off[item + 1] - o0;
+    if (ragged_refused(status)) {   // malformed offsets (k_sponge_ragged): zero digests, no message byte read; wave-uniform
+      if (live && !odd && C::writer() && j < NABI) out[item * NABI + j] = 0u;
+      continue;
+    }
+    const uint64_t o0 = off[item], len = ragged_len(off, item);   // (a decreasing pair reads as an empty message)
     const uint8_t* msg = msgs + o0 * (BYTES ? 1 : NABI * 4);
-    const size_t num = BYTES ? (len + F::kChunk - 1) / F::kChunk : len;
-    const unsigned tot = unsigned(num + (num % RATE == 0 ? 0 : 1));   // + the padding element 1 (never for RATE = 1)
-    const unsigned steps = wave_max(tot);
+    const uint64_t num = BYTES ? len / F::kChunk + (len % F::kChunk ? 1 : 0) : len;
+    const uint64_t tot = num + (num % RATE == 0 ? 0 : 1);   // + the padding element 1 (never for RATE = 1); 64-bit like the lengths
+    const uint64_t steps = wave_max(tot);
     uint32_t x = 0, y = 0;   // this column's part of the state: x = state[col], y = state[W/2 + col]
 #pragma nounroll
-    for (unsigned e = 0; e < steps; e++) {
+    for (uint64_t e = 0; e < steps; e++) {
       const bool active = e < tot, have = e < num;
       uint32_t el;
       if (BYTES) {

@@ -525,9 +525,25 @@ __device__ __forceinline__ void store_digest(uint4* __restrict__ dst, const type
 // device-side bucketing of anemoi_hash_bytes_ragged_bucketed_dev (k_ragged_hist / _scan / _place below): messages by
 // descending block count, so that the lanes of a wavefront run out of blocks together.
 // BYTES: messages of bytes, offsets in bytes (Sponge::hash); else messages of ABI elements, offsets in ELEMENTS (hash_field).
+// MALFORMED OFFSETS (they are device memory: no host check can see them).  A decreasing pair is read as an EMPTY message
+// (ragged_len), never as a length that wrapped.  `status` (may be null): the word the bucketing kernels leave -- non-zero
+// when a pair decreases or the last offset lies beyond the blob; the launch then writes the empty message's digest (zero
+// words) for every message and reads no message byte.  Block counts stay 64-bit: a message of >= 2^32 blocks (>= 133 GB)
+// fits this GPU's memory, a narrowing would hash a prefix of it.
+__device__ __forceinline__ uint64_t ragged_len(const uint64_t* __restrict__ off, size_t item) {
+  const uint64_t o0 = off[item], o1 = off[item + 1];
+  return o1 >= o0 ? o1 - o0 : 0;
+}
+__device__ __forceinline__ bool ragged_refused(const uint32_t* __restrict__ status) { return status && *status != 0; }
+template <int Q>
+__device__ __forceinline__ void store_zero_digest(uint4* __restrict__ dst) {
+#pragma unroll
+  for (int q = 0; q < Q; q++) dst[q] = make_uint4(0, 0, 0, 0);
+}
 template <int FIELD, bool BYTES>
 ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off, size_t n,
-                                   uint4* __restrict__ out, PermConsts pc, const uint32_t* __restrict__ order) {
+                                   uint4* __restrict__ out, PermConsts pc, const uint32_t* __restrict__ order,
+                                   const uint32_t* __restrict__ status) {
   using F = FieldC<FIELD>;
   using A = ArithFor<FIELD>;
   constexpr int WIN = KernelCfg<F::N>::WIN;  // Anemoi-2-1: RATE = 1, a block is one element
@@ -536,17 +552,21 @@ ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint6
   const int cnt = n - blk0 < size_t(kBlock) ? int(n - blk0) : kBlock;
   const size_t slot = blk0 + (threadIdx.x < cnt ? threadIdx.x : 0);  // idle lanes redo item blk0
   const size_t item = order ? size_t(order[slot]) : slot;
-  const uint64_t o0 = off[item], len = off[item + 1] - o0;
+  if (ragged_refused(status)) {  // wave-uniform
+    if (threadIdx.x < cnt) store_zero_digest<A::NABI / 4>(out + item * (A::NABI / 4));
+    return;
+  }
+  const uint64_t o0 = off[item], len = ragged_len(off, item);
   const uint8_t* msg = msgs + o0 * (BYTES ? 1 : A::NABI * 4);
-  const size_t num = BYTES ? (len + F::kChunk - 1) / F::kChunk : len;  // RATE = 1: no padding element ever
-  const unsigned blocks = (unsigned)num, bmax = wave_max(blocks);
+  const uint64_t num = BYTES ? len / F::kChunk + (len % F::kChunk ? 1 : 0) : len;  // RATE = 1: no padding element ever
+  const uint64_t blocks = num, bmax = wave_max(blocks);
   typename A::Fe st[2], dig;
   A::set_zero(st[0]);
   A::set_zero(st[1]);
   A::set_zero(dig);  // the empty message hashes to state[0] of the zero state
   const LdsTable<A> tab = make_table<A>(lds);
 #pragma nounroll
-  for (unsigned b = 0; b < bmax; b++) {
+  for (uint64_t b = 0; b < bmax; b++) {
     if (b < blocks) {
       typename A::Fe el;
       sponge_element<F, A, BYTES>(el, msg, b, 0, num, len);
@@ -566,7 +586,8 @@ ANEMOI_KERNEL void k_sponge_ragged(const uint8_t* __restrict__ msgs, const uint6
 
 template <int FIELD, bool BYTES>
 ANEMOI_KERNEL void k_sponge_ragged_pair(const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ off, size_t n,
-                                        uint4* __restrict__ out, PermConsts pc, const uint32_t* __restrict__ order) {
+                                        uint4* __restrict__ out, PermConsts pc, const uint32_t* __restrict__ order,
+                                        const uint32_t* __restrict__ status) {
   using F = FieldC<FIELD>;
   using A = ArithFor<FIELD>;
   constexpr int WIN = KernelCfg<F::N>::WIN, RATE = 3;
@@ -577,18 +598,22 @@ ANEMOI_KERNEL void k_sponge_ragged_pair(const uint8_t* __restrict__ msgs, const 
   const int s = threadIdx.x >> 1;
   const size_t slot = st0 + (s < cnt ? s : 0);  // idle lane pairs redo item st0
   const size_t item = order ? size_t(order[slot]) : slot;
-  const uint64_t o0 = off[item], len = off[item + 1] - o0;
+  if (ragged_refused(status)) {  // wave-uniform
+    if (!odd && s < cnt) store_zero_digest<A::NABI / 4>(out + item * (A::NABI / 4));
+    return;
+  }
+  const uint64_t o0 = off[item], len = ragged_len(off, item);
   const uint8_t* msg = msgs + o0 * (BYTES ? 1 : A::NABI * 4);
-  const size_t num = BYTES ? (len + F::kChunk - 1) / F::kChunk : len;
-  const size_t total = num + (num % RATE == 0 ? 0 : 1);  // + the padding element 1
-  const unsigned blocks = (unsigned)((total + RATE - 1) / RATE), bmax = wave_max(blocks);
+  const uint64_t num = BYTES ? len / F::kChunk + (len % F::kChunk ? 1 : 0) : len;
+  const uint64_t total = num + (num % RATE == 0 ? 0 : 1);  // + the padding element 1 (num <= 2^64 - 3 then: no wrap)
+  const uint64_t blocks = total / RATE + (total % RATE ? 1 : 0), bmax = wave_max(blocks);
   typename A::Fe x, y, dig;
   A::set_zero(x);
   A::set_zero(y);
   A::set_zero(dig);
   const LdsTable<A> tab = make_table<A>(lds);
 #pragma nounroll
-  for (unsigned b = 0; b < bmax; b++) {
+  for (uint64_t b = 0; b < bmax; b++) {
     // state[0] -> even.x, state[1] -> odd.x, state[2] -> even.y; both lanes of a pair see the same message
     static_for<0, RATE>([&](auto r) {
       const size_t e = size_t(b) * RATE + r;
@@ -721,8 +746,9 @@ struct FieldOps {
   // messages of different lengths: message i = bytes [off[i], off[i+1]) of d_msgs
   // (bytes: byte messages and byte offsets; else messages of ABI elements and offsets in elements)
   // d_order: null, or n 32-bit message indices (slot j works on message d_order[j] and writes out[d_order[j]])
+  // d_status: null, or the bucketing's status word (non-zero: malformed offsets -- zero digests, no message byte read)
   hipError_t (*sponge_ragged)(int width, int bytes, const void* d_msgs, const void* d_off, size_t n, void* d_out, PermConsts pc,
-                              const void* d_order, hipStream_t s);
+                              const void* d_order, const void* d_status, hipStream_t s);
   hipError_t (*mont_convert)(int to, const void* d_in, void* d_out, size_t count, hipStream_t s);
   hipError_t (*merkle_climb)(const void* d_leaves, const void* d_index, const void* d_paths, unsigned depth, size_t n,
                              void* d_out, PermConsts pc, hipStream_t s);
@@ -932,38 +958,39 @@ struct Launch {
   }
 
   static hipError_t sponge_ragged(int width, int bytes, const void* msgs, const void* off, size_t n, void* out, PermConsts pc,
-                                  const void* order, hipStream_t s) {
+                                  const void* order, const void* status, hipStream_t s) {
     if (!n) return hipSuccess;
-    return bytes ? sponge_ragged_as<true>(width, msgs, off, n, out, pc, order, s)
-                 : sponge_ragged_as<false>(width, msgs, off, n, out, pc, order, s);
+    return bytes ? sponge_ragged_as<true>(width, msgs, off, n, out, pc, order, status, s)
+                 : sponge_ragged_as<false>(width, msgs, off, n, out, pc, order, status, s);
   }
   template <bool BYTES>
   static hipError_t sponge_ragged_as(int width, const void* msgs, const void* off, size_t n, void* out, PermConsts pc,
-                                     const void* order, hipStream_t s) {
+                                     const void* order, const void* status, hipStream_t s) {
     // small batches: the latency kernels, at the cut-offs of the equal-length sponge (sponge_seg above)
     const uint8_t* m = (const uint8_t*)msgs;
     const uint64_t* o = (const uint64_t*)off;
     const uint32_t* ord = (const uint32_t*)order;
+    const uint32_t* st = (const uint32_t*)status;
     if (width == 2 && n <= coop2d_max_items(pc.simds)) {  // two messages per wavefront
       const size_t groups = (n + 1) / 2;
-      k_sponge_ragged_coop<FIELD, 2, BYTES, 32><<<unsigned(groups < 65536 ? groups : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      k_sponge_ragged_coop<FIELD, 2, BYTES, 32><<<unsigned(groups < 65536 ? groups : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord, st);
       return hipGetLastError();
     }
     if (width == 4 && n <= coop2d43_max_items(pc.simds)) {  // one 4-3 message per wavefront
-      k_sponge_ragged_coop<FIELD, 4, BYTES, 32><<<unsigned(n < 65536 ? n : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      k_sponge_ragged_coop<FIELD, 4, BYTES, 32><<<unsigned(n < 65536 ? n : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord, st);
       return hipGetLastError();
     }
     if (n <= coop_sponge_max_items(pc.simds)) {  // four (2-1) / two (4-3) messages per wavefront on the scan
       const size_t groups = width == 2 ? (n + 3) / 4 : (n + 1) / 2;
       const unsigned g = unsigned(groups < 65536 ? groups : 65536);
-      if (width == 2) k_sponge_ragged_coop<FIELD, 2, BYTES, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
-      else k_sponge_ragged_coop<FIELD, 4, BYTES, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord);
+      if (width == 2) k_sponge_ragged_coop<FIELD, 2, BYTES, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord, st);
+      else k_sponge_ragged_coop<FIELD, 4, BYTES, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord, st);
       return hipGetLastError();
     }
     if (width == 2)
-      k_sponge_ragged<FIELD, BYTES><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>(m, o, n, (uint4*)out, pc, ord);
+      k_sponge_ragged<FIELD, BYTES><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>(m, o, n, (uint4*)out, pc, ord, st);
     else
-      k_sponge_ragged_pair<FIELD, BYTES><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(m, o, n, (uint4*)out, pc, ord);
+      k_sponge_ragged_pair<FIELD, BYTES><<<pair_grid(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>(m, o, n, (uint4*)out, pc, ord, st);
     return hipGetLastError();
   }
 

@@ -467,16 +467,33 @@ __global__ void k_assemble4(const uint4* __restrict__ cur, const uint4* __restri
 // exclusive scan from the longest bucket down, placement by atomic cursor (four launches, nothing else).  Not stable -- equal block counts land in
 // any order, which costs nothing -- and every digest goes back to its message's own index.
 constexpr int kRaggedBins = 1 << 16;
+// The scratch of the bucketed forms: [0] the STATUS word (+ 3 words of padding), kRaggedBins counters, n message indices.
+// Status: 0, or ANEMOI_RAGGED_DECREASING | ANEMOI_RAGGED_BEYOND_EXTENT -- the offsets are device memory, so only the device
+// can see that they are malformed: k_ragged_hist, which reads every pair anyway, flags a decreasing pair and a last offset
+// beyond the caller-given extent of the blob; the sponge kernels read the word (one scalar load) and, if it is set, write
+// zero digests without reading a message byte.  A malformed pair counts as an empty message here, so that histogram and
+// placement agree and `order` is a permutation of 0 .. n-1 whatever the offsets hold.
+constexpr int kRaggedHead = 4;
 __device__ __forceinline__ uint32_t ragged_bin(const uint64_t* __restrict__ off, size_t i, uint32_t block_units) {
-  const uint64_t blocks = (off[i + 1] - off[i] + block_units - 1) / block_units;
+  const uint64_t o0 = off[i], o1 = off[i + 1];
+  const uint64_t len = o1 >= o0 ? o1 - o0 : 0;
+  const uint64_t blocks = len / block_units + (len % block_units ? 1 : 0);   // (no len + block_units - 1: len may be near 2^64)
   return uint32_t(kRaggedBins - 1) - uint32_t(blocks < uint64_t(kRaggedBins - 1) ? blocks : uint64_t(kRaggedBins - 1));   // bin 0 = the longest
 }
 // (a kernel, not hipMemsetAsync: captured into a hipGraph, the memset node in front of these kernels did not zero the
 // counters on replay -- the second replay then placed its indices behind the first one's and wrote past the scratch)
-__global__ void k_ragged_zero(uint32_t* __restrict__ bins) { bins[size_t(blockIdx.x) * blockDim.x + threadIdx.x] = 0; }
-__global__ void k_ragged_hist(const uint64_t* __restrict__ off, size_t n, uint32_t block_units, uint32_t* __restrict__ bins) {
+__global__ void k_ragged_zero(uint32_t* __restrict__ head) {   // status word, padding and counters
   const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) atomicAdd(&bins[ragged_bin(off, i, block_units)], 1u);
+  if (i < size_t(kRaggedHead + kRaggedBins)) head[i] = 0;
+}
+__global__ void k_ragged_hist(const uint64_t* __restrict__ off, size_t n, uint64_t extent, uint32_t block_units,
+                              uint32_t* __restrict__ status, uint32_t* __restrict__ bins) {
+  const size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t bad = off[i + 1] < off[i] ? uint32_t(ANEMOI_RAGGED_DECREASING) : 0u;
+  if (i == n - 1 && off[n] > extent) bad |= uint32_t(ANEMOI_RAGGED_BEYOND_EXTENT);
+  if (bad) atomicOr(status, bad);
+  atomicAdd(&bins[ragged_bin(off, i, block_units)], 1u);
 }
 // counts -> first slot of each bin (one workgroup of 1 024 threads, 64 bins each)
 __global__ __launch_bounds__(1024) void k_ragged_scan(uint32_t* __restrict__ bins) {
@@ -660,7 +677,7 @@ int merkle_host(TreeShape ts, const uint64_t* leaves, unsigned depth, uint64_t* 
 
 extern "C" {
 
-int anemoi_abi_version(void) { return 4; }
+int anemoi_abi_version(void) { return 100 * ANEMOI_ABI_MAJOR + ANEMOI_ABI_MINOR; }   // the rule: include/anemoi_mi355x.h
 
 int anemoi_device_count(void) {
   int n = 0;
@@ -1177,7 +1194,7 @@ static int ragged_dev(int field, int width, int bytes, const void* d_msgs, const
   if (n && (!d_out || !d_offsets || !d_msgs)) return ANEMOI_ERR_ARG;
   PermConsts pc;
   if ((rc = get_consts(field, width, &pc))) return rc;
-  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, bytes, d_msgs, d_offsets, n, d_out, pc, nullptr, (hipStream_t)stream));
+  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, bytes, d_msgs, d_offsets, n, d_out, pc, nullptr, nullptr, (hipStream_t)stream));
   return ANEMOI_OK;
 }
 int anemoi_hash_bytes_ragged_dev(int field, int width, const void* d_msgs, const void* d_offsets, size_t n, void* d_out,
@@ -1189,10 +1206,10 @@ int anemoi_hash_field_ragged_dev(int field, int width, const void* d_elems, cons
   return ragged_dev(field, width, 0, d_elems, d_offsets, n, d_out, stream);
 }
 
-size_t anemoi_ragged_scratch_bytes(size_t n) { return (size_t(kRaggedBins) + n) * sizeof(uint32_t); }
+size_t anemoi_ragged_scratch_bytes(size_t n) { return (size_t(kRaggedHead) + size_t(kRaggedBins) + n) * sizeof(uint32_t); }
 
-static int ragged_bucketed_dev(int field, int width, int bytes, const void* d_msgs, const void* d_offsets, size_t n, void* d_out,
-                               void* d_scratch, size_t scratch_bytes, void* stream) {
+static int ragged_bucketed_dev(int field, int width, int bytes, const void* d_msgs, size_t msgs_len, const void* d_offsets, size_t n,
+                               void* d_out, void* d_scratch, size_t scratch_bytes, void* stream) {
   int rc = check_instance(field, width);
   if (rc) return rc;
   if (n && (!d_out || !d_offsets || !d_msgs || !d_scratch)) return ANEMOI_ERR_ARG;
@@ -1202,27 +1219,27 @@ static int ragged_bucketed_dev(int field, int width, int bytes, const void* d_ms
   PermConsts pc;
   if ((rc = get_consts(field, width, &pc))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  uint32_t* bins = (uint32_t*)d_scratch;      // kRaggedBins counters, then the order: n message indices
+  uint32_t* status = (uint32_t*)d_scratch;    // the status word (+ padding), kRaggedBins counters, then the order: n message indices
+  uint32_t* bins = status + kRaggedHead;
   uint32_t* order = bins + kRaggedBins;
   // what one permutation absorbs, in the unit of the offsets: bytes, or elements
   const uint32_t block_units = uint32_t(width - 1) * (bytes ? uint32_t(anemoi::field_ops(field)->chunk) : 1u);
   const unsigned grid = unsigned((n + 255) / 256);
-  static_assert(kRaggedBins % 256 == 0, "k_ragged_zero: whole workgroups");
-  k_ragged_zero<<<kRaggedBins / 256, 256, 0, s>>>(bins);
-  k_ragged_hist<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, block_units, bins);
+  k_ragged_zero<<<(kRaggedHead + kRaggedBins + 255) / 256, 256, 0, s>>>(status);
+  k_ragged_hist<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, uint64_t(msgs_len), block_units, status, bins);
   k_ragged_scan<<<1, 1024, 0, s>>>(bins);
   k_ragged_place<<<grid, 256, 0, s>>>((const uint64_t*)d_offsets, n, block_units, bins, order);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, bytes, d_msgs, d_offsets, n, d_out, pc, order, s));
+  HIP_TRY(anemoi::field_ops(field)->sponge_ragged(width, bytes, d_msgs, d_offsets, n, d_out, pc, order, status, s));
   return ANEMOI_OK;
 }
-int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void* d_msgs, const void* d_offsets, size_t n,
+int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void* d_msgs, size_t msgs_len, const void* d_offsets, size_t n,
                                           void* d_out, void* d_scratch, size_t scratch_bytes, void* stream) {
-  return ragged_bucketed_dev(field, width, 1, d_msgs, d_offsets, n, d_out, d_scratch, scratch_bytes, stream);
+  return ragged_bucketed_dev(field, width, 1, d_msgs, msgs_len, d_offsets, n, d_out, d_scratch, scratch_bytes, stream);
 }
-int anemoi_hash_field_ragged_bucketed_dev(int field, int width, const void* d_elems, const void* d_offsets, size_t n,
+int anemoi_hash_field_ragged_bucketed_dev(int field, int width, const void* d_elems, size_t elems_len, const void* d_offsets, size_t n,
                                           void* d_out, void* d_scratch, size_t scratch_bytes, void* stream) {
-  return ragged_bucketed_dev(field, width, 0, d_elems, d_offsets, n, d_out, d_scratch, scratch_bytes, stream);
+  return ragged_bucketed_dev(field, width, 0, d_elems, elems_len, d_offsets, n, d_out, d_scratch, scratch_bytes, stream);
 }
 
 int anemoi_merkle_root_dev(int field, const void* d_leaves, unsigned depth, void* d_scratch, void* d_root,

@@ -81,7 +81,16 @@ enum {
 #define ANEMOI_ERR_DEVICE (-4) /* no such device, or a HIP call failed: see anemoi_last_error() */
 #define ANEMOI_ERR_ALLOC (-5)  /* device or host allocation failed */
 
-/* ---- introspection ---------------------------------------------------------------------- */
+/* ---- introspection ----------------------------------------------------------------------
+ * ABI VERSION RULE.  anemoi_abi_version() = 100 x ANEMOI_ABI_MAJOR + ANEMOI_ABI_MINOR of the header the LIBRARY was built
+ * from.  MAJOR moves when an existing function changes its signature, its buffer layout or the meaning of an argument or of
+ * a result (a caller must be re-read and re-compiled); MINOR moves, and MAJOR stays, when functions, options or error codes
+ * are only ADDED.  A caller compiled against (M, m) may use a library that answers 100 x M + m' with m' >= m, and nothing
+ * else.  History: 4 (56 functions); 11 functions were added in round 5 without moving it (by this rule: 4.1); 5.0 = the two
+ * `_ragged_bucketed_dev` forms take the extent of the message blob and leave a status word in the scratch, whose size grew
+ * by 16 bytes (67 functions). */
+#define ANEMOI_ABI_MAJOR 5
+#define ANEMOI_ABI_MINOR 0
 int anemoi_abi_version(void);
 int anemoi_device_count(void);               /* visible HIP devices, or a negative error */
 const char *anemoi_strerror(int code);
@@ -312,23 +321,38 @@ int anemoi_hash_bytes_dev(int field, int width, const void *d_msgs, size_t msg_l
  * GIVEN ORDER, 64 (Anemoi-2-1) or 32 (4-3) consecutive messages per wavefront, and a wavefront runs as long as its longest
  * message: right for batches that are already grouped by length; for anything else use the bucketed form below.  Small
  * batches (up to the cut-offs of the equal-length sponge: options coop2d_max / coop2d43_max / coop_sponge_max) take the
- * latency kernels like an equal-length batch does -- 2 or 4 (Anemoi-2-1) / 1 or 2 (4-3) messages per wavefront. */
+ * latency kernels like an equal-length batch does -- 2 or 4 (Anemoi-2-1) / 1 or 2 (4-3) messages per wavefront.
+ * The offsets are DEVICE memory, which no host-side check can read (the host forms answer ANEMOI_ERR_ARG for malformed
+ * offsets before any device work).  What the device does with them: a pair that DECREASES (offsets[i+1] < offsets[i]) is
+ * hashed as an EMPTY message -- its length is never the wrapped difference.  An offset beyond the end of d_msgs cannot be
+ * recognised here, because this form is not told where d_msgs ends: that is undefined behaviour on the device (a memory
+ * fault).  A caller that cannot vouch for its offsets uses the bucketed form, which is told and checks. */
 int anemoi_hash_bytes_ragged_dev(int field, int width, const void *d_msgs, const void *d_offsets, size_t n, void *d_out,
                                  void *stream);
 /* The same on an UNSORTED device-resident batch: the library first orders the messages by descending block count on the
  * device (a counting sort: zero, histogram, scan, placement -- four small launches on `stream`), runs the ragged kernels in
- * that order and writes every digest to its message's own index.  d_scratch: anemoi_ragged_scratch_bytes(n) bytes of
- * device memory the caller owns (65 536 counters + n 32-bit indices; 4-byte aligned), contents undefined afterwards; n < 2^32.  Only
- * kernel launches on `stream`: capturable like the other `_dev` functions (tests/test_gpu_capture.py replays it). */
+ * that order and writes every digest to its message's own index.  msgs_len: the bytes d_msgs holds.  d_scratch:
+ * anemoi_ragged_scratch_bytes(n) bytes of device memory the caller owns (a status word, 65 536 counters, n 32-bit indices;
+ * 4-byte aligned), contents undefined afterwards except for the status word; n < 2^32.  Only kernel launches on `stream`:
+ * capturable like the other `_dev` functions (tests/test_gpu_capture.py replays it).
+ * MALFORMED OFFSETS are reported, not followed: the histogram launch, which reads every offset pair anyway, sets bits in
+ * the FIRST 32-BIT WORD OF d_scratch -- ANEMOI_RAGGED_DECREASING if some offsets[i+1] < offsets[i], ANEMOI_RAGGED_BEYOND_EXTENT
+ * if offsets[n] > msgs_len -- and the sponge launch, seeing the word set, writes n all-zero digests and reads no byte of
+ * d_msgs.  The function itself returns ANEMOI_OK (it only enqueues); the caller reads the word once the work on `stream`
+ * has completed (hipMemcpyAsync of 4 bytes behind the call): 0 = every digest is valid.  With non-decreasing offsets and
+ * offsets[n] <= msgs_len every read lies inside d_msgs, so no device-resident value can make this call fault. */
+#define ANEMOI_RAGGED_DECREASING 1
+#define ANEMOI_RAGGED_BEYOND_EXTENT 2
 size_t anemoi_ragged_scratch_bytes(size_t n);
-int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void *d_msgs, const void *d_offsets, size_t n, void *d_out,
-                                          void *d_scratch, size_t scratch_bytes, void *stream);
+int anemoi_hash_bytes_ragged_bucketed_dev(int field, int width, const void *d_msgs, size_t msgs_len, const void *d_offsets,
+                                          size_t n, void *d_out, void *d_scratch, size_t scratch_bytes, void *stream);
 /* The two calls above for messages of field elements (hash_field): d_elems = elements in ABI form (8-byte aligned),
- * d_offsets = n + 1 uint64 offsets counted in ELEMENTS.  Same kernels, same routing, same scratch. */
+ * d_offsets = n + 1 uint64 offsets counted in ELEMENTS, elems_len = the ELEMENTS d_elems holds.  Same kernels, same routing,
+ * same scratch, same treatment of malformed offsets. */
 int anemoi_hash_field_ragged_dev(int field, int width, const void *d_elems, const void *d_offsets, size_t n, void *d_out,
                                  void *stream);
-int anemoi_hash_field_ragged_bucketed_dev(int field, int width, const void *d_elems, const void *d_offsets, size_t n, void *d_out,
-                                          void *d_scratch, size_t scratch_bytes, void *stream);
+int anemoi_hash_field_ragged_bucketed_dev(int field, int width, const void *d_elems, size_t elems_len, const void *d_offsets,
+                                          size_t n, void *d_out, void *d_scratch, size_t scratch_bytes, void *stream);
 /* d_scratch: at least 2^depth elements; d_root: 1 element; d_leaves is not modified. */
 int anemoi_merkle_root_dev(int field, const void *d_leaves, unsigned depth, void *d_scratch, void *d_root,
                            void *stream);

@@ -685,9 +685,9 @@ struct Walk {
       }
       // ragged: two lanes, one message ends two blocks before the other (its state runs on unobserved)
       std::vector<uint64_t> off{0, ch - 3, ch - 3 + 3 * ch};
-      lane_case("k_sponge_ragged<bytes>", 2, [&] { k_sponge_ragged<FIELD, true>(bytes.data(), off.data(), 2, out.data(), pc, nullptr); });
+      lane_case("k_sponge_ragged<bytes>", 2, [&] { k_sponge_ragged<FIELD, true>(bytes.data(), off.data(), 2, out.data(), pc, nullptr, nullptr); });
       std::vector<uint64_t> eoff{0, 1, 5};   // messages of 1 and 4 elements
-      lane_case("k_sponge_ragged<elements>", 2, [&] { k_sponge_ragged<FIELD, false>((const uint8_t*)in.data(), eoff.data(), 2, out.data(), pc, nullptr); });
+      lane_case("k_sponge_ragged<elements>", 2, [&] { k_sponge_ragged<FIELD, false>((const uint8_t*)in.data(), eoff.data(), 2, out.data(), pc, nullptr, nullptr); });
       lane_case("k_merkle_climb depth 3", 1, [&] { k_merkle_climb<FIELD>(in.data(), index.data(), st.data(), 3, 1, out.data(), pc); });
     }
     // ---- Anemoi-4-3: a state per lane (the form no launcher uses, kept compiling) and per lane PAIR (the shipped one)
@@ -718,9 +718,9 @@ struct Walk {
         }
       }
       std::vector<uint64_t> off{0, 2, 2 + 9 * ch};
-      lane_case("k_sponge_ragged_pair<bytes>", 4, [&] { k_sponge_ragged_pair<FIELD, true>(bytes.data(), off.data(), 2, out.data(), pc, nullptr); });
+      lane_case("k_sponge_ragged_pair<bytes>", 4, [&] { k_sponge_ragged_pair<FIELD, true>(bytes.data(), off.data(), 2, out.data(), pc, nullptr, nullptr); });
       std::vector<uint64_t> eoff{0, 2, 9};   // 2 elements (padded to 3) and 7 (padded to 9)
-      lane_case("k_sponge_ragged_pair<elements>", 4, [&] { k_sponge_ragged_pair<FIELD, false>((const uint8_t*)in.data(), eoff.data(), 2, out.data(), pc, nullptr); });
+      lane_case("k_sponge_ragged_pair<elements>", 4, [&] { k_sponge_ragged_pair<FIELD, false>((const uint8_t*)in.data(), eoff.data(), 2, out.data(), pc, nullptr, nullptr); });
     }
     // ---- instances given at run time: NUM_COLUMNS = 1 .. 16, constants through k_generic_prepare as the product does
     {
@@ -792,11 +792,11 @@ struct Walk {
       {   // ragged: two messages in one wavefront (lane 0 and lane LPI: the next row / row pair), one ends two blocks early
         const std::vector<uint64_t> off{0, 3 * ch + 5, 4 * ch + 7};
         w.template coop_case<LPI>("k_sponge_ragged_coop<2,bytes," + t, [&](const PermConsts& pc) {
-          k_sponge_ragged_coop<FIELD, 2, true, LPI>(bytes.data(), off.data(), 2, out.data(), pc, nullptr);
+          k_sponge_ragged_coop<FIELD, 2, true, LPI>(bytes.data(), off.data(), 2, out.data(), pc, nullptr, nullptr);
         }, {0, LPI});
         const std::vector<uint64_t> eoff{0, 4, 5};   // 4 elements beside 1
         w.template coop_case<LPI>("k_sponge_ragged_coop<2,elements," + t, [&](const PermConsts& pc) {
-          k_sponge_ragged_coop<FIELD, 2, false, LPI>((const uint8_t*)in.data(), eoff.data(), 2, out.data(), pc, nullptr);
+          k_sponge_ragged_coop<FIELD, 2, false, LPI>((const uint8_t*)in.data(), eoff.data(), 2, out.data(), pc, nullptr, nullptr);
         }, {0, LPI});
       }
     }
@@ -832,19 +832,19 @@ struct Walk {
         const std::vector<uint64_t> off{0, 7 * ch + 5, 9 * ch + 5};
         const std::vector<int> lanes = LPI == 16 ? std::vector<int>{0, 16, 32, 48} : std::vector<int>{0, 32};
         w.template coop_case<LPI>("k_sponge_ragged_coop<4,bytes," + t, [&](const PermConsts& pc) {
-          k_sponge_ragged_coop<FIELD, 4, true, LPI>(bytes.data(), off.data(), LPI == 16 ? 2 : 1, out.data(), pc, nullptr);
+          k_sponge_ragged_coop<FIELD, 4, true, LPI>(bytes.data(), off.data(), LPI == 16 ? 2 : 1, out.data(), pc, nullptr, nullptr);
         }, lanes);
         if (LPI == 32)   // ... and the short message alone on the fold kernel
           w.template coop_case<LPI>("k_sponge_ragged_coop<4,bytes," + t + " short message", [&](const PermConsts& pc) {
-            k_sponge_ragged_coop<FIELD, 4, true, LPI>(bytes.data(), off.data() + 1, 1, out.data(), pc, nullptr);
+            k_sponge_ragged_coop<FIELD, 4, true, LPI>(bytes.data(), off.data() + 1, 1, out.data(), pc, nullptr, nullptr);
           }, lanes);
         const std::vector<uint64_t> eoff{0, 7, 9};   // 7 elements (padded to 9) beside 2 (padded to 3)
         w.template coop_case<LPI>("k_sponge_ragged_coop<4,elements," + t, [&](const PermConsts& pc) {
-          k_sponge_ragged_coop<FIELD, 4, false, LPI>((const uint8_t*)in.data(), eoff.data(), LPI == 16 ? 2 : 1, out.data(), pc, nullptr);
+          k_sponge_ragged_coop<FIELD, 4, false, LPI>((const uint8_t*)in.data(), eoff.data(), LPI == 16 ? 2 : 1, out.data(), pc, nullptr, nullptr);
         }, lanes);
         if (LPI == 32)
           w.template coop_case<LPI>("k_sponge_ragged_coop<4,elements," + t + " short message", [&](const PermConsts& pc) {
-            k_sponge_ragged_coop<FIELD, 4, false, LPI>((const uint8_t*)in.data(), eoff.data() + 1, 1, out.data(), pc, nullptr);
+            k_sponge_ragged_coop<FIELD, 4, false, LPI>((const uint8_t*)in.data(), eoff.data() + 1, 1, out.data(), pc, nullptr, nullptr);
           }, lanes);
       }
     }

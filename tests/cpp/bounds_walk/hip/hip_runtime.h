@@ -34,6 +34,11 @@ static inline int __shfl(int v, int src_lane) { return (int)walk::exchange((uint
 static inline int __shfl_xor(int v, int mask) { return (int)walk::exchange((uint32_t)v, int(threadIdx.x) ^ mask); }
 static inline unsigned __shfl(unsigned v, int src_lane) { return walk::exchange(v, src_lane); }
 static inline unsigned __shfl_xor(unsigned v, int mask) { return walk::exchange(v, int(threadIdx.x) ^ mask); }
+static inline unsigned long __shfl_xor(unsigned long v, int mask) {   // (64-bit block counts of the ragged sponge: two halves)
+  const unsigned long lo = walk::exchange((uint32_t)v, int(threadIdx.x) ^ mask);
+  const unsigned long hi = walk::exchange((uint32_t)(v >> 32), int(threadIdx.x) ^ mask);
+  return hi << 32 | lo;
+}
 // DPP: only the control the lane-private kernels use (quad_perm:[1,0,3,2] = swap with the pair neighbour)
 static inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
   if (ctrl == 0xB1) return (int)walk::exchange((uint32_t)src, int(threadIdx.x) ^ 1);

@@ -36,7 +36,7 @@ def test_binding_covers_every_declared_symbol(A):
 
 
 def test_introspection(A, params):
-    assert A.lib.anemoi_abi_version() == 4
+    assert A.lib.anemoi_abi_version() == 500        # 100 x major + minor: the rule is in the header
     for fid, name in enumerate(FIELD_IDS):
         assert A.lib.anemoi_field_name(fid).decode() == name
         assert A.field_id(name) == fid
@@ -79,16 +79,16 @@ def test_argument_errors_need_no_device(A):
     assert L.anemoi_clock_sampler_wait_dev(big.ctypes.data, 0, None) == -3 and L.anemoi_clock_sampler_wait_dev(big.ctypes.data, 10001, None) == -3
     assert L.anemoi_clock_stamp_dev(None, None) == -3
     assert L.anemoi_clock_stamp_dev(buf.ctypes.data + 4, None) == -3
-    assert L.anemoi_ragged_scratch_bytes(1000) == (65536 + 1000) * 4
-    assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 2, p, p, 4, q, None, 0, None) == -3         # no scratch
-    assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 2, p, p, 4, q, big.ctypes.data, 64, None) == -3   # scratch too small
-    assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 2, p, p, 4, q, big.ctypes.data + 2, big.nbytes - 2, None) == -3
-    assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 2, p, p, 0, q, big.ctypes.data, big.nbytes, None) == 0   # nothing to do
-    assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 3, p, p, 4, q, big.ctypes.data, big.nbytes, None) == -2
+    assert L.anemoi_ragged_scratch_bytes(1000) == (4 + 65536 + 1000) * 4
+    assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 2, p, 64, p, 4, q, None, 0, None) == -3         # no scratch
+    assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 2, p, 64, p, 4, q, big.ctypes.data, 64, None) == -3   # scratch too small
+    assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 2, p, 64, p, 4, q, big.ctypes.data + 2, big.nbytes - 2, None) == -3
+    assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 2, p, 64, p, 0, q, big.ctypes.data, big.nbytes, None) == 0   # nothing to do
+    assert L.anemoi_hash_bytes_ragged_bucketed_dev(0, 3, p, 64, p, 4, q, big.ctypes.data, big.nbytes, None) == -2
     # ... the same checks in front of the hash_field forms; decreasing element offsets
-    assert L.anemoi_hash_field_ragged_bucketed_dev(0, 2, p, p, 4, q, None, 0, None) == -3
-    assert L.anemoi_hash_field_ragged_bucketed_dev(0, 2, p, p, 4, q, big.ctypes.data, 64, None) == -3
-    assert L.anemoi_hash_field_ragged_bucketed_dev(0, 2, p, p, 0, q, big.ctypes.data, big.nbytes, None) == 0
+    assert L.anemoi_hash_field_ragged_bucketed_dev(0, 2, p, 64, p, 4, q, None, 0, None) == -3
+    assert L.anemoi_hash_field_ragged_bucketed_dev(0, 2, p, 64, p, 4, q, big.ctypes.data, 64, None) == -3
+    assert L.anemoi_hash_field_ragged_bucketed_dev(0, 2, p, 64, p, 0, q, big.ctypes.data, big.nbytes, None) == 0
     assert L.anemoi_hash_field_ragged_dev(7, 2, p, p, 4, q, None) == -1
     assert L.anemoi_hash_field_ragged_dev(0, 6, p, p, 4, q, None) == -2
     assert L.anemoi_hash_field_ragged_dev(0, 2, None, p, 4, q, None) == -3

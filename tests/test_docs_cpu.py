@@ -58,6 +58,15 @@ def test_quoted_counts_are_the_headers():
         text = open(os.path.join(ROOT, doc)).read()
         for m in re.finditer(r"(\d+) functions", text):
             assert int(m.group(1)) == n, "%s says %s functions, the header declares %d" % (doc, m.group(1), n)
-    abi = re.search(r"ABI (\d+)", open(os.path.join(ROOT, "DESIGN.md")).read())
+    # the ABI version: DESIGN.md quotes "ABI <major>.<minor>", the header defines both, the library computes its answer from
+    # the header's defines (the rule -- what moves which -- is the header's "ABI VERSION RULE" paragraph)
+    raw = open(os.path.join(ROOT, "include", "anemoi_mi355x.h")).read()
+    major = int(re.search(r"#define ANEMOI_ABI_MAJOR (\d+)", raw).group(1))
+    minor = int(re.search(r"#define ANEMOI_ABI_MINOR (\d+)", raw).group(1))
+    assert "ABI VERSION RULE" in raw
+    abi = re.search(r"ABI (\d+)\.(\d+)", open(os.path.join(ROOT, "DESIGN.md")).read())
+    assert abi and (int(abi.group(1)), int(abi.group(2))) == (major, minor)
     src = open(os.path.join(ROOT, "anemoi-rust_amd", "csrc", "capi.hip")).read()
-    assert abi and ("anemoi_abi_version(void) { return %s; }" % abi.group(1)) in src
+    assert "anemoi_abi_version(void) { return 100 * ANEMOI_ABI_MAJOR + ANEMOI_ABI_MINOR; }" in src
+    # ... and the header's own count of its functions, in the rule's history line
+    assert ("(%d functions)" % n) in raw

@@ -73,7 +73,7 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
         assert A.lib.anemoi_merkle_root_dev(jub, d_leaves.data_ptr(), depth, d_scratch.data_ptr(), d_root.data_ptr(), s) == 0
         assert A.lib.anemoi_hash_bytes_dev(bn, 4, d_msgs.data_ptr(), mlen, nmsg, d_dig.data_ptr(), s) == 0
         assert A.lib.anemoi_jive_compress_k_dev(bls, 2, 2, d_states.data_ptr(), d_out.data_ptr(), nst, s) == 0
-        assert A.lib.anemoi_hash_bytes_ragged_bucketed_dev(jub, 2, d_rag.data_ptr(), d_rag_offs.data_ptr(), nrag, d_rag_out.data_ptr(),
+        assert A.lib.anemoi_hash_bytes_ragged_bucketed_dev(jub, 2, d_rag.data_ptr(), d_rag.numel(), d_rag_offs.data_ptr(), nrag, d_rag_out.data_ptr(),
                                                            d_rag_scr.data_ptr(), rag_need, s) == 0
 
     def check(what):
@@ -180,7 +180,7 @@ def test_every_other_dev_entry_point_replays_like_a_direct_call(oracle, params):
         assert lib.anemoi_to_montgomery_dev(jub, p(out["from_m"]), p(out["to_m"]), n, s) == 0
         assert lib.anemoi_hash_bytes_ragged_dev(jub, 2, p(d["rbytes"]), p(d_boffs), n, p(out["rb"]), s) == 0
         assert lib.anemoi_hash_field_ragged_dev(jub, 4, p(d["relems"]), p(d_eoffs), n, p(out["re"]), s) == 0
-        assert lib.anemoi_hash_field_ragged_bucketed_dev(jub, 2, p(d["relems"]), p(d_eoffs), n, p(out["reb"]), p(d_scr), need, s) == 0
+        assert lib.anemoi_hash_field_ragged_bucketed_dev(jub, 2, p(d["relems"]), d["relems"].numel() // L, p(d_eoffs), n, p(out["reb"]), p(d_scr), need, s) == 0
         prep.permutation_dev(p(d["gperm"]), n, s)
         prep.compress_k_dev(2, p(d["perm"]), p(out["gjive"]), n, s)       # (reads what anemoi_permutation_dev left in place)
         prep.hash_field_dev(1, p(d["hf"]), epm, n, p(out["ghf"]), s)

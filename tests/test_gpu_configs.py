@@ -346,7 +346,7 @@ def test_small_ragged_batches_on_every_kernel_family(A, oracle):
                     for bucketed in (0, 1):
                         d_out = torch.zeros(n * L, dtype=torch.int64, device=dev)
                         if bucketed:
-                            rc = A.lib.anemoi_hash_bytes_ragged_bucketed_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n,
+                            rc = A.lib.anemoi_hash_bytes_ragged_bucketed_dev(fid, width, d_blob.data_ptr(), d_blob.numel(), d_offs.data_ptr(), n,
                                                                              d_out.data_ptr(), d_scr.data_ptr(), need, s)
                         else:
                             rc = A.lib.anemoi_hash_bytes_ragged_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n, d_out.data_ptr(), s)
@@ -395,7 +395,7 @@ def test_ragged_hash_field_on_every_kernel_family(A, oracle):
                     for bucketed in (0, 1):
                         d_out = torch.zeros(n * L, dtype=torch.int64, device=dev)
                         if bucketed:
-                            rc = A.lib.anemoi_hash_field_ragged_bucketed_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n,
+                            rc = A.lib.anemoi_hash_field_ragged_bucketed_dev(fid, width, d_blob.data_ptr(), d_blob.numel() // L, d_offs.data_ptr(), n,
                                                                              d_out.data_ptr(), d_scr.data_ptr(), need, s)
                         else:
                             rc = A.lib.anemoi_hash_field_ragged_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n, d_out.data_ptr(), s)
@@ -451,10 +451,10 @@ def test_unsorted_device_resident_ragged_batch_is_bucketed_on_the_device(A, orac
         d_out = torch.zeros(n * L, dtype=torch.int64, device=dev)
         d_ref = torch.zeros(n * L, dtype=torch.int64, device=dev)
         need = A.lib.anemoi_ragged_scratch_bytes(n)
-        assert need == (65536 + n) * 4
+        assert need == (4 + 65536 + n) * 4       # the status word (+ padding), the counters, the order
         d_scr = torch.empty(need, dtype=torch.uint8, device=dev)
         assert A.lib.anemoi_init(0, fid, width) == 0
-        args = (fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n, d_out.data_ptr(), d_scr.data_ptr())
+        args = (fid, width, d_blob.data_ptr(), d_blob.numel(), d_offs.data_ptr(), n, d_out.data_ptr(), d_scr.data_ptr())
         assert A.lib.anemoi_hash_bytes_ragged_bucketed_dev(*args, need - 1, s) == -3
         assert A.lib.anemoi_hash_bytes_ragged_bucketed_dev(*args, need, s) == 0
         assert A.lib.anemoi_hash_bytes_ragged_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n, d_ref.data_ptr(), s) == 0
@@ -463,10 +463,102 @@ def test_unsorted_device_resident_ragged_batch_is_bucketed_on_the_device(A, orac
         assert (got == d_ref.cpu().numpy().view(np.uint64).reshape(n, L)).all(), (field, width)
         for i in list(range(0, n, 37)) + [n // 2, n - 1]:
             assert (got[i] == oracle.hash_bytes(fid, width, msgs[i])).all(), (field, width, i, lens[i])
-        order = d_scr.cpu().numpy()[65536 * 4:].view(np.uint32)
+        assert d_scr.cpu().numpy()[:4].view(np.uint32)[0] == 0                 # the status word: well-formed offsets
+        order = d_scr.cpu().numpy()[(4 + 65536) * 4:].view(np.uint32)
         assert sorted(order.tolist()) == list(range(n))                       # a permutation ...
         blocks = [-(-lens[i] // ((width - 1) * inst.chunk)) for i in order]
         assert all(a >= b for a, b in zip(blocks, blocks[1:]))                 # ... by descending block count
+
+
+def test_malformed_device_offsets_are_reported_not_followed(A, oracle):
+    """Round 5's review, item 3.  Offsets that live in DEVICE memory cannot be checked by the host (the host forms answer
+    ANEMOI_ERR_ARG: test above); before this round a decreasing pair became a length of ~2^64 and the lane read far past
+    the blob -- a memory fault that kills the process, from a library whose header promises "no function aborts".  Now:
+      * the bucketed forms (which are told where the blob ends) flag a decreasing pair / a last offset beyond the extent in
+        the FIRST WORD OF THE SCRATCH (k_ragged_hist reads every pair anyway), and the sponge launch, seeing the word set,
+        writes zero digests and reads no message byte -- whatever the offsets hold (2^63, 2^64 - 1);
+      * the in-order forms read a decreasing pair as an EMPTY message (never the wrapped difference): that message's digest
+        is the empty message's, its neighbours' are their own.
+    Every kernel family (fold, scan, lane-private, by batch size), both widths, bytes and elements; the scratch's status
+    goes back to 0 on the next well-formed call.  Run once per change -- a fault here would be the bug itself."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(6003)
+    DEC, EXT = 1, 2   # ANEMOI_RAGGED_DECREASING, ANEMOI_RAGGED_BEYOND_EXTENT
+
+    def status_of(d_scr):
+        return int(d_scr[:4].cpu().numpy().view(np.uint32)[0])
+
+    for field, width, n in (("jubjub", 2, 150), ("jubjub", 2, 3000), ("jubjub", 2, 5000), ("bls12_381", 2, 4500),
+                            ("bn_254", 4, 90), ("bn_254", 4, 2000), ("bn_254", 4, 4300)):
+        fid, inst = FIELD_IDS.index(field), A.Anemoi(field, width)
+        L, c = inst.limbs, inst.chunk
+        for unit in ("bytes", "elements"):
+            if unit == "bytes":
+                lens = rng.integers(0, 3 * c, size=n)
+                blob = rng.integers(0, 256, size=int(lens.sum()) + 1, dtype=np.uint8)
+                d_blob, extent = torch.from_numpy(blob).to(dev), blob.size
+                fn_b, fn_o = A.lib.anemoi_hash_bytes_ragged_bucketed_dev, A.lib.anemoi_hash_bytes_ragged_dev
+                ref = lambda a, b: oracle.hash_bytes(fid, width, blob[a:b].tobytes())
+            else:
+                lens = rng.integers(0, 5, size=n)
+                blob = rng.integers(0, 1 << 60, size=(int(lens.sum()) + 1, L), dtype=np.uint64)    # limbs < 2^60: canonical
+                d_blob, extent = torch.from_numpy(blob.view(np.int64).reshape(-1)).to(dev), blob.shape[0]
+                fn_b, fn_o = A.lib.anemoi_hash_field_ragged_bucketed_dev, A.lib.anemoi_hash_field_ragged_dev
+                ref = lambda a, b: oracle.hash_field(fid, width, blob[a:b])
+            good = np.zeros(n + 1, dtype=np.uint64)
+            good[1:] = np.cumsum(lens, dtype=np.uint64)
+            need = A.lib.anemoi_ragged_scratch_bytes(n)
+            d_scr = torch.empty(need, dtype=torch.uint8, device=dev)
+            d_out = torch.empty(n * L, dtype=torch.int64, device=dev)
+            assert A.lib.anemoi_init(0, fid, width) == 0
+
+            def bucketed(offs, ext):
+                d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+                d_out.fill_(-1)
+                assert fn_b(fid, width, d_blob.data_ptr(), ext, d_offs.data_ptr(), n, d_out.data_ptr(), d_scr.data_ptr(), need, s) == 0
+                torch.cuda.synchronize()
+                return status_of(d_scr), d_out.cpu().numpy().view(np.uint64).reshape(n, L)
+
+            st, want = bucketed(good, extent)
+            assert st == 0 and (want[n // 3] == ref(int(good[n // 3]), int(good[n // 3 + 1]))).all(), (field, width, unit)
+            k = n // 2
+            cases = {}
+            if int(good[k]) > 0:                                                               # a pair that decreases (a little)
+                o = good.copy(); o[k + 1] = max(int(good[k]) - 3, 0)
+                cases["decreasing"] = (o, extent, DEC)
+            o = good.copy(); o[k + 1] = 1 << 63                                                # ... and hugely: the next pair decreases
+            cases["2^63"] = (o, extent, DEC)
+            o = good.copy(); o[0] = (1 << 64) - 1                                              # the first pair wraps to a tiny length
+            cases["2^64-1 first"] = (o, extent, DEC)
+            o = good.copy(); o[n] += 1000                                                      # non-decreasing, but past the blob
+            cases["beyond"] = (o, extent, EXT)
+            o = good.copy(); o[k + 1:] += np.uint64(1 << 40)                                   # a jump in the middle: past the blob
+            cases["jump"] = (o, extent, EXT)
+            if good[n] > 0:
+                cases["extent too small"] = (good, int(good[n]) - 1, EXT)
+            o = good.copy(); o[n] = 1 << 62; o[n - 1] = (1 << 62) + 7
+            cases["both"] = (o, extent, DEC | EXT)
+            for name, (offs, ext, bits) in cases.items():
+                st, got = bucketed(offs, ext)
+                assert st == bits, (field, width, n, unit, name, st)
+                assert not got.any(), (field, width, n, unit, name)          # every digest zero: nothing was hashed, nothing read
+            st, again = bucketed(good, extent)                                # the same scratch, well-formed offsets again
+            assert st == 0 and (again == want).all(), (field, width, n, unit)
+            # the in-order form on the SMALL decrease (everything stays inside the blob): message k is the empty message,
+            # message k + 1 what its own pair says, the others untouched
+            if "decreasing" in cases:
+                offs = cases["decreasing"][0]
+                d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+                d_out.fill_(-1)
+                assert fn_o(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n, d_out.data_ptr(), s) == 0
+                torch.cuda.synchronize()
+                got = d_out.cpu().numpy().view(np.uint64).reshape(n, L)
+                assert not got[k].any(), (field, width, n, unit)
+                assert (got[k + 1] == ref(int(offs[k + 1]), int(offs[k + 2]))).all(), (field, width, n, unit)
+                keep = np.ones(n, dtype=bool); keep[k] = keep[k + 1] = False
+                assert (got[keep] == want[keep]).all(), (field, width, n, unit)
 
 
 def test_pinned_caller_buffers_are_used_directly(A, oracle):

@@ -107,7 +107,7 @@ def test_ragged_batch_with_offsets_beyond_4_gib_host_and_device(A, oracle):
     for bucketed in (0, 1):
         d_out = torch.zeros(n * 4, dtype=torch.int64, device=dev)
         if bucketed:
-            rc = A.lib.anemoi_hash_bytes_ragged_bucketed_dev(fid, 4, d_blob.data_ptr(), d_offs.data_ptr(), n, d_out.data_ptr(),
+            rc = A.lib.anemoi_hash_bytes_ragged_bucketed_dev(fid, 4, d_blob.data_ptr(), d_blob.numel(), d_offs.data_ptr(), n, d_out.data_ptr(),
                                                              d_scr.data_ptr(), need, s)
         else:
             rc = A.lib.anemoi_hash_bytes_ragged_dev(fid, 4, d_blob.data_ptr(), d_offs.data_ptr(), n, d_out.data_ptr(), s)

@@ -131,7 +131,7 @@ if "ragged" in sys.argv or len(sys.argv) == 1:
     for _ in range(3):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(s)
-        assert A.lib.anemoi_hash_bytes_ragged_bucketed_dev(f3, 4, d_b.data_ptr(), d_off.data_ptr(), nm, d_o.data_ptr(), d_scr.data_ptr(),
+        assert A.lib.anemoi_hash_bytes_ragged_bucketed_dev(f3, 4, d_b.data_ptr(), d_b.numel(), d_off.data_ptr(), nm, d_o.data_ptr(), d_scr.data_ptr(),
                                                            d_scr.numel(), s.cuda_stream) == 0
         b.record(s)
         torch.cuda.synchronize()
@@ -206,7 +206,7 @@ if "ragged" in sys.argv or len(sys.argv) == 1:
         dres[label, "in order"] = dev_ms(lambda: A.lib.anemoi_hash_bytes_ragged_dev(f3, 4, d_b.data_ptr(), d_f.data_ptr(), nm, d_o.data_ptr(), s.cuda_stream))
         ref = d_o.clone()
         dres[label, "bucketed"] = dev_ms(lambda: A.lib.anemoi_hash_bytes_ragged_bucketed_dev(
-            f3, 4, d_b.data_ptr(), d_f.data_ptr(), nm, d_o.data_ptr(), d_scr.data_ptr(), d_scr.numel(), s.cuda_stream))
+            f3, 4, d_b.data_ptr(), d_b.numel(), d_f.data_ptr(), nm, d_o.data_ptr(), d_scr.data_ptr(), d_scr.numel(), s.cuda_stream))
         assert torch.equal(ref, d_o)
         del d_b, d_f
     print("  device-resident: pre-sorted, in order %.1f ms | unsorted, in order %.1f ms | unsorted, bucketed on the device %.1f ms "

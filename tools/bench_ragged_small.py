@@ -48,7 +48,7 @@ for field, width in (("jubjub", 2), ("bls12_381", 2), ("bn_254", 4), ("bls12_381
         d_scr = torch.empty(A.lib.anemoi_ragged_scratch_bytes(n), dtype=torch.uint8, device=dev)
 
         def call(o):
-            return A.lib.anemoi_hash_bytes_ragged_bucketed_dev(fid, width, d_blob.data_ptr(), d_offs.data_ptr(), n, o.data_ptr(),
+            return A.lib.anemoi_hash_bytes_ragged_bucketed_dev(fid, width, d_blob.data_ptr(), d_blob.numel(), d_offs.data_ptr(), n, o.data_ptr(),
                                                                d_scr.data_ptr(), d_scr.numel(), stream.cuda_stream)
         t_new = timed(lambda: call(d_out[0]))
         with A.options(**LANE_PRIVATE):
