@@ -14,7 +14,16 @@
  * form with R = 2^(64 L), fully reduced (< p).  That is byte-for-byte the in-memory form of the
  * reference's `Felt` = arkworks `Fp<MontBackend<_, L>, L>` (src/<field>/mod.rs:1-3), so a Rust
  * caller passes `slice.as_ptr()` unchanged.  Non-Rust callers convert canonical integers with
- * anemoi_to_montgomery / anemoi_from_montgomery.  Inputs must be fully reduced; outputs always are.
+ * anemoi_to_montgomery / anemoi_from_montgomery.
+ * UNREDUCED INPUTS.  arkworks keeps a `Felt` below p, so a Rust caller never sends anything else; a C caller's buffer
+ * holds whatever words it holds.  The contract: ANY 64 L-bit pattern X in an element buffer is taken as X mod p (up to
+ * 13.7 p on ed_on_bls12_377, 152 p on bls12_377) -- every entry point returns exactly what it returns for the reduced
+ * value, and every OUTPUT element is fully reduced.  This is proven, not assumed: the walk of the kernels' lazy-reduction
+ * bounds starts every ABI input at 2^(64 L) - 1 (csrc/BOUNDS.md, tests/test_bounds_walk.py), and
+ * tests/test_gpu_parity.py::test_unreduced_abi_inputs_are_taken_mod_p feeds p, p + 1, 2^(64 L) - 1 ... to every entry
+ * point under every kernel routing.  Two places hand the caller's BYTES through instead of a value, and say so below:
+ * level 0 of a retained Merkle tree (and a depth-0 root) is a copy of the leaves as given; the `root` argument of the
+ * verify functions is compared bytewise with a canonical value, so it must be reduced (every root the library returns is).
  *
  * OWNERSHIP / THREADING: the caller allocates and owns every buffer.  The library owns only its
  * per-device constant tables and a pool of "lanes" (three non-blocking HIP streams, reusable device
@@ -248,7 +257,8 @@ int anemoi_merkle_tree(int field, const uint64_t *leaves, unsigned depth, uint64
 int anemoi_merkle_path(int field, const uint64_t *tree, unsigned depth, size_t index, uint64_t *path);
 
 /* Batched path verification on the GPU: item i recomputes the root from leaves[i], indices[i] and its
- * depth-element path (depth sequential merges per lane) and ok[i] = (it equals `root`). */
+ * depth-element path (depth sequential merges per lane) and ok[i] = (it equals `root`, byte for byte: `root` must be a
+ * reduced element -- leaves and paths may hold any pattern, see UNREDUCED INPUTS). */
 int anemoi_merkle_verify_batch(int field, const uint64_t *leaves, const uint64_t *indices, const uint64_t *paths,
                                unsigned depth, size_t n, const uint64_t *root, uint8_t *ok, int device);
 

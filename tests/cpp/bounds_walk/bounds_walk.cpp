@@ -365,6 +365,18 @@ struct LayoutInfo {
   // Montgomery product, digit-serial (mont29.h, coop29.h, coop2d.h's mul_exact): (a b + m p) / R' with m <= R' - 1
   Big mont(const Big& a, const Big& b) const { return (a * b + (R - Big(1)) * p).shr(L::W * L::NL); }
   Big chunk_max() const { return Big::pow2(8 * F::kChunk) - Big(1); }   // chunk_to_fe: kChunk bytes, or fewer and a 0x01
+  // What an ABI element may hold.  The contract (include/anemoi_mi355x.h, since round 6): ANY 64 L-bit pattern, taken
+  // mod p -- arkworks keeps its elements reduced (src/<field>/mod.rs:1-3), but the words of a caller's buffer are
+  // whatever the caller left there, and the kernels must not overflow an accumulator because of them.  So the walk
+  // starts every ABI input at 2^(64 L) - 1 (13.7 p on ed_on_bls12_377, 152 p on bls12_377), not at p - 1.
+  // -DWALK_ABI_INPUT_REDUCED restores the old starting point (the table then shows what the wider contract costs).
+  Big abi_max() const {
+#ifdef WALK_ABI_INPUT_REDUCED
+    return p - Big(1);
+#else
+    return Big::pow2(32 * F::N) - Big(1);
+#endif
+  }
 };
 
 #define WALK_SITE const char *file = __builtin_FILE(), int line = __builtin_LINE()
@@ -432,10 +444,10 @@ struct BoundsWalkArith {
   static void set_one(Fe& x, WALK_SITE) { set(x, walk::log_op("one", file, line, zero(), zero(), Info::get().One)); }
   static void set_zero(Fe& x, WALK_SITE) { set(x, walk::log_op("zero", file, line, zero(), zero(), zero())); }
   static void add_delta(Fe& r, const Fe& a, WALK_SITE) { add_k(r, a, L::Delta, file, line); }
-  // the words are whatever the staging area holds; the contract is "a fully reduced ABI element" (include/anemoi_mi355x.h)
+  // the words are whatever the staging area holds; the contract is "any 64 L-bit pattern" (LayoutInfo::abi_max)
   static void from_abi(Fe& r, const uint32_t (&)[NABI], WALK_SITE) {
     const Info& I = Info::get();
-    const Big x = I.p - Big(1);
+    const Big x = I.abi_max();
     set(r, walk::log_op("from_abi", file, line, x, I.In, I.mont(x, I.In)));
   }
   static void to_abi(uint32_t (&w)[NABI], const Fe& a, WALK_SITE) {
@@ -547,7 +559,7 @@ struct BoundsWalkCoop {
   }
   static uint32_t from_abi(uint32_t, const K&, WALK_SITE) {
     const Info& I = Info::get();
-    const Big x = I.p - Big(1);
+    const Big x = I.abi_max();
     return tag(walk::log_op("from_abi", file, line, x, I.In, product(x, I.In)));
   }
   static uint32_t to_mont(uint32_t, const K&, WALK_SITE) {   // a chunk of a byte message (k_sponge_coop)

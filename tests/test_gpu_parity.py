@@ -189,6 +189,92 @@ def test_montgomery_conversion(A, oracle, params, field):
     assert (A.from_montgomery(field, mont) == canon).all()
 
 
+# ---------------------------------------------------------------- the input contract: ANY 64 L-bit pattern is taken mod p
+
+def unreduced(p, L, count, seed):
+    """`count` raw 64 L-bit integers, most of them NOT below p: p, p + 1, 2 p - 1 ... 2^(64 L) - 1, multiples of p, random
+    values of the whole range (on ed_on_bls12_377 up to 13.7 p, on bls12_377 up to 152 p), a few reduced ones between"""
+    top = 1 << (64 * L)
+    rng = random.Random(seed)
+    fixed = [p, p + 1, top - 1, top - 2, min(2 * p - 1, top - 1), min(2 * p, top - 1), (top - 1) // p * p, (top - 1) // p * p - 1,
+             0, 1, p - 1, top >> 1]
+    vals = fixed + [rng.randrange(p, top) for _ in range(count)]
+    for i in range(len(fixed), len(vals), 7):
+        vals[i] = rng.randrange(p)
+    return vals[:count]
+
+
+@pytest.mark.parametrize("kernels", ["default", "row", "lane"])
+@pytest.mark.parametrize("field,width", INSTANCES)
+def test_unreduced_abi_inputs_are_taken_mod_p(A, oracle, params, field, width, kernels):
+    """Round 5's review, item 4.  arkworks keeps a `Felt` below p (src/<field>/mod.rs:1-3; `from_le_bytes_mod_order`,
+    anemoi_2_1/hasher.rs:57), but a C-ABI sees whatever words the caller's buffer holds.  The header now says: any 64 L-bit
+    pattern X is taken as X mod p -- proven by the bounds walk, which starts every ABI input at 2^(64 L) - 1
+    (tests/cpp/bounds_walk/bounds_walk.cpp: LayoutInfo::abi_max; csrc/BOUNDS.md rows `from_abi`), and checked here on
+    the device: every entry point that reads ABI elements, under the three kernel routings, fed with p, p + 1,
+    2^(64 L) - 1, multiples of p and random patterns of the whole range, must return EXACTLY what the oracle returns
+    for the reduced values."""
+    fid, p, L = FIELD_IDS.index(field), int(params[field]["modulus"]), params[field]["u64_limbs"]
+    inst = A.Anemoi(field, width)
+    with knobs(**LATENCY_KERNELS[kernels]):
+        for n in (1, 3, 70):
+            raw_i = unreduced(p, L, n * width, 31 * fid + width + n)
+            raw = A.ints_to_limbs(raw_i, L).reshape(n, width, L)
+            red = A.ints_to_limbs([v % p for v in raw_i], L).reshape(n, width, L)
+            assert n < 3 or (raw != red).any()
+            assert (inst.compress_batch(raw) == oracle.compress_batch(fid, width, red, k=2, threads=8)).all(), n
+            gp, gs = inst.permutation_batch(raw), inst.sbox_layer_batch(raw)
+            for i in (0, n // 2, n - 1):
+                assert (gp[i] == oracle.permutation(fid, width, red[i])).all(), (n, i)
+                assert (gs[i] == oracle.sbox_layer(fid, width, red[i])).all(), (n, i)
+            if width == 4:
+                assert (inst.compress_k_batch(raw, 4) == oracle.compress_batch(fid, width, red, k=4, threads=8)).all(), n
+            else:
+                assert (inst.merge_batch(raw) == oracle.compress_batch(fid, width, red, k=2, threads=8)[:, 0]).all(), n
+            # hash_field: equal-length messages of 1 .. 7 elements (the rate block and its padding), and a ragged batch
+            for epm in (1, 2, 3, 4, 7):
+                e_i = unreduced(p, L, n * epm, 5 * fid + epm + n)
+                e_raw = A.ints_to_limbs(e_i, L).reshape(n, epm, L)
+                e_red = A.ints_to_limbs([v % p for v in e_i], L).reshape(n, epm, L)
+                assert (inst.hash_field_batch(e_raw) == oracle.hash_field_batch(fid, width, e_red, threads=8)).all(), (n, epm)
+            counts = [(3 * i + n) % 6 for i in range(n)]
+            e_i = unreduced(p, L, sum(counts) + 1, 77 + fid)
+            e_raw, e_red = A.ints_to_limbs(e_i, L), A.ints_to_limbs([v % p for v in e_i], L)
+            at, m_raw, m_red = 0, [], []
+            for c in counts:
+                m_raw.append(e_raw[at:at + c]), m_red.append(e_red[at:at + c])
+                at += c
+            got = inst.hash_field_ragged(m_raw)
+            for i in range(n):
+                assert (got[i] == oracle.hash_field(fid, width, m_red[i])).all(), (n, i, counts[i])
+    # conversions (always on the 32-bit-limb form): x R and x / R of the reduced value, canonical
+    v_i = unreduced(p, L, 100, 900 + fid)
+    v_raw, v_red = A.ints_to_limbs(v_i, L), A.ints_to_limbs([v % p for v in v_i], L)
+    assert (A.to_montgomery(field, v_raw) == A.to_montgomery(field, v_red)).all()
+    assert (A.from_montgomery(field, v_raw) == A.from_montgomery(field, v_red)).all()
+    assert (A.from_montgomery(field, v_raw) == A.ints_to_limbs(oracle.mont_to_ints(fid, v_red), L)).all()
+    if width == 2:
+        # Merkle: unreduced leaves (the retained level 0 is the caller's own bytes, every level above it is canonical), and
+        # path verification with unreduced leaves AND unreduced siblings against the canonical root (the `root` argument
+        # itself is compared as bytes with a canonical value: it must be reduced, as every root the library returns is)
+        with knobs(**LATENCY_KERNELS[kernels]):
+            depth = 5
+            l_i = unreduced(p, L, 1 << depth, 4000 + fid)
+            l_raw, l_red = A.ints_to_limbs(l_i, L), A.ints_to_limbs([v % p for v in l_i], L)
+            root = oracle.merkle_root(fid, l_red, depth)
+            assert (inst.merkle_root(l_raw, depth) == root).all()
+            lv_raw, lv_red = inst.merkle_tree(l_raw, depth), [a.copy() for a in inst.merkle_tree(l_red, depth)]
+            assert (lv_raw[0] == l_raw).all() and all((a == b).all() for a, b in zip(lv_raw[1:], lv_red[1:]))
+            idx = [0, 5, 17, 31]
+            paths = np.stack([inst.merkle_path(lv_red, depth, i) for i in idx])
+            paths[:, 0] = l_raw[[i ^ 1 for i in idx]]          # the bottom sibling as the caller's unreduced bytes
+            top_room = ((1 << (64 * L)) - 1) // p               # ... and every other sibling shifted by a multiple of p
+            lifted = [[v + (k % top_room) * p for k, v in enumerate(A.limbs_to_ints(pth[1:]), 1)] for pth in paths]
+            paths[:, 1:] = np.stack([A.ints_to_limbs(row, L) for row in lifted])
+            assert inst.merkle_verify_batch(l_raw[idx], idx, paths, depth, root).all()
+            assert not inst.merkle_verify_batch(l_raw[idx], [i ^ 2 for i in idx], paths, depth, root).any()
+
+
 @pytest.mark.parametrize("field", ["jubjub", "bls12_381", "vesta"])
 def test_merkle_vs_oracle(A, oracle, params, field):
     fid, p, L = FIELD_IDS.index(field), int(params[field]["modulus"]), params[field]["u64_limbs"]

@@ -43,8 +43,8 @@ def test_headline_kernel_runs_three_waves_per_simd(rows):
 
 
 def test_committed_table_matches_the_built_library(rows):
-    """profiles/r05/kernel_resources.csv is what the round's documents quote: it must describe this build"""
-    path = os.path.join(ROOT, "profiles", "r05", "kernel_resources.csv")
+    """profiles/r06/kernel_resources.csv is what the round's documents quote: it must describe this build"""
+    path = os.path.join(ROOT, "profiles", "r06", "kernel_resources.csv")
     if not os.path.exists(path):
         pytest.skip("table not committed yet")
     import csv
