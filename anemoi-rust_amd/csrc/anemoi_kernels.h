@@ -221,9 +221,42 @@ ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out,
 // queue the faster XCDs would take more.  Measured in one process: 100.00 against 100.24 ms at 2^20, 200.56 against
 // 200.27 at 2^21 -- nothing.  Whatever makes the slowest sampled clock the right one, it is not static dealing.
 // `queue[0]` must be 0 at launch; grid = the resident workgroups of the device.
+// XCD ACCOUNTING (round 6; tools/exp_xcd_accounting.py, profiles/r06/xcd_accounting.txt): what each of the 8 XCDs did in
+// one launch -- blocks worked, the wall clock (100 MHz) of its first block's start and of its last block's end, and the
+// wall ticks / shader cycles its blocks took in sum (their ratio is the clock the XCD held UNDER ITS OWN WORK, measured by
+// the work's own wavefronts; cycles per block says whether a block costs the same everywhere).  Five atomics per block of
+// ~19 ms.  `acct` (may be null): 8 records; the caller zeroes them and sets first_start to ~0.
+struct XcdAcct {
+  unsigned long long blocks, first_start, last_end, wall_ticks, cycles;
+};
+struct AcctScope {
+  XcdAcct* a;
+  unsigned long long t0, c0;
+  __device__ __forceinline__ explicit AcctScope(XcdAcct* acct) : a(acct), t0(0), c0(0) {
+    if (a) t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void end() {
+    if (!a || threadIdx.x) return;
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    XcdAcct& x = a[__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 7u];   // XCC_ID (as k_clock_sampler reads it)
+    atomicAdd(&x.blocks, 1ull);
+    atomicMin(&x.first_start, t0);
+    atomicMax(&x.last_end, t1);
+    atomicAdd(&x.wall_ticks, t1 - t0);
+    atomicAdd(&x.cycles, c1 - c0);
+  }
+};
+// the shipped kernel's dealing (block = blockIdx.x) with the accounting around it
+template <int FIELD, int W, int K>
+ANEMOI_KERNEL void k_jive_acct(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n, PermConsts pc, XcdAcct* acct) {
+  extern __shared__ uint4 lds[];
+  AcctScope sc(acct);
+  jive_block<FIELD, W, K>(in, out, n, pc, blockIdx.x, lds);
+  sc.end();
+}
 template <int FIELD, int W, int K>
 ANEMOI_KERNEL void k_jive_queue(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n, PermConsts pc,
-                                uint32_t* __restrict__ queue) {
+                                uint32_t* __restrict__ queue, XcdAcct* acct) {
   extern __shared__ uint4 lds[];
   const uint32_t nblocks = uint32_t((n + kBlock - 1) / kBlock);
   for (;;) {
@@ -231,7 +264,9 @@ ANEMOI_KERNEL void k_jive_queue(const uint4* __restrict__ in, uint4* __restrict_
     if (threadIdx.x == 0) b = atomicAdd(queue, 1u);
     b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
     if (b >= nblocks) break;
+    AcctScope sc(acct);
     jive_block<FIELD, W, K>(in, out, n, pc, b, lds);
+    sc.end();
     __syncthreads();   // the staging area is reused by the next block
   }
 }
@@ -240,13 +275,15 @@ ANEMOI_KERNEL void k_jive_queue(const uint4* __restrict__ in, uint4* __restrict_
 // gets through its share sooner and so draws more tickets, the surplus workgroups of the slower ones find none and leave.
 template <int FIELD, int W, int K>
 ANEMOI_KERNEL void k_jive_ticket(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n, PermConsts pc,
-                                 uint32_t* __restrict__ counter) {
+                                 uint32_t* __restrict__ counter, XcdAcct* acct) {
   extern __shared__ uint4 lds[];
   uint32_t b = 0;
   if (threadIdx.x == 0) b = atomicAdd(counter, 1u);
   b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
   if (b >= uint32_t((n + kBlock - 1) / kBlock)) return;
+  AcctScope sc(acct);
   jive_block<FIELD, W, K>(in, out, n, pc, b, lds);
+  sc.end();
 }
 #endif  // ANEMOI_AB_BUILD
 
@@ -770,7 +807,8 @@ struct FieldOps {
   hipError_t (*warmup)(int width, void* d_buf, void* d_out, size_t n, PermConsts pc, hipStream_t s);
 #if ANEMOI_AB_BUILD
   // Jive 2-1 with the blocks handed out by a counter (d_queue[0] = 0 at launch); `wgs` resident workgroups
-  hipError_t (*jive_queue)(const void* d_in, void* d_out, size_t n, PermConsts pc, uint32_t* d_queue, unsigned wgs, hipStream_t s);
+  // wgs = 0: the shipped static dealing (k_jive_acct); d_acct: null or 8 XcdAcct records (see there)
+  hipError_t (*jive_queue)(const void* d_in, void* d_out, size_t n, PermConsts pc, uint32_t* d_queue, unsigned wgs, void* d_acct, hipStream_t s);
 #endif
 };
 
@@ -1084,11 +1122,14 @@ struct Launch {
   }
 
 #if ANEMOI_AB_BUILD
-  static hipError_t jive_queue(const void* in, void* out, size_t n, PermConsts pc, uint32_t* queue, unsigned wgs, hipStream_t s) {
-    if (wgs >= grid_for(n))   // at least one workgroup per block: the ticket form (one block per workgroup, surplus workgroups leave)
-      k_jive_ticket<FIELD, 2, 2><<<wgs, kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc, queue);
+  static hipError_t jive_queue(const void* in, void* out, size_t n, PermConsts pc, uint32_t* queue, unsigned wgs, void* acct, hipStream_t s) {
+    XcdAcct* a = (XcdAcct*)acct;
+    if (wgs == 0)   // the shipped dealing, accounted
+      k_jive_acct<FIELD, 2, 2><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc, a);
+    else if (wgs >= grid_for(n))   // at least one workgroup per block: the ticket form (one block per workgroup, surplus workgroups leave)
+      k_jive_ticket<FIELD, 2, 2><<<wgs, kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc, queue, a);
     else
-      k_jive_queue<FIELD, 2, 2><<<wgs, kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc, queue);
+      k_jive_queue<FIELD, 2, 2><<<wgs, kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc, queue, a);
     return hipGetLastError();
   }
 #endif

@@ -1153,14 +1153,24 @@ int anemoi_jive_compress_k_dev(int field, int width, int k, const void* d_in, vo
 
 #if ANEMOI_AB_BUILD
 // laboratory builds only (not in the header): Jive 2-1 with a work queue; d_queue = one uint32 owned by the caller
-int anemoi_x_jive_queue_dev(int field, const void* d_in, void* d_out, size_t n, void* d_queue, unsigned wgs, void* stream) {
+static int x_jive_queue(int field, const void* d_in, void* d_out, size_t n, void* d_queue, unsigned wgs, void* d_acct, void* stream) {
   int rc = check_instance(field, 2);
   if (rc) return rc;
   PermConsts pc;
   if ((rc = get_consts(field, 2, &pc))) return rc;
-  HIP_TRY(hipMemsetAsync(d_queue, 0, 4, (hipStream_t)stream));
-  HIP_TRY(anemoi::field_ops(field)->jive_queue(d_in, d_out, n, pc, (uint32_t*)d_queue, wgs, (hipStream_t)stream));
+  if (wgs) HIP_TRY(hipMemsetAsync(d_queue, 0, 4, (hipStream_t)stream));
+  HIP_TRY(anemoi::field_ops(field)->jive_queue(d_in, d_out, n, pc, (uint32_t*)d_queue, wgs, d_acct, (hipStream_t)stream));
   return ANEMOI_OK;
+}
+int anemoi_x_jive_queue_dev(int field, const void* d_in, void* d_out, size_t n, void* d_queue, unsigned wgs, void* stream) {
+  if (!wgs) return ANEMOI_ERR_ARG;
+  return x_jive_queue(field, d_in, d_out, n, d_queue, wgs, nullptr, stream);
+}
+// ... and with the per-XCD accounting (anemoi_kernels.h: XcdAcct; d_acct = 8 records of 5 uint64, prepared by the caller):
+// wgs = 0 is the SHIPPED static dealing, wgs < blocks the queue, wgs >= blocks the tickets
+int anemoi_x_jive_acct_dev(int field, const void* d_in, void* d_out, size_t n, void* d_queue, unsigned wgs, void* d_acct, void* stream) {
+  if (!d_acct) return ANEMOI_ERR_ARG;
+  return x_jive_queue(field, d_in, d_out, n, d_queue, wgs, d_acct, stream);
 }
 #endif
 

@@ -85,7 +85,8 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
         got_out = d_out.cpu().numpy().view(np.uint64).reshape(nst, 6)
         assert (got_out == oracle.compress_batch(bls, 2, states, threads=8).reshape(nst, 6)).all(), what + ": Jive outputs"
         got_rag = d_rag_out.cpu().numpy().view(np.uint64).reshape(nrag, 4)
-        order = d_rag_scr.cpu().numpy()[65536 * 4:].view(np.uint32)
+        assert d_rag_scr[:4].cpu().numpy().view(np.uint32)[0] == 0, "%s: the status word is set" % what
+        order = d_rag_scr.cpu().numpy()[(4 + 65536) * 4:].view(np.uint32)     # status word (+ padding), counters, order
         assert sorted(order.tolist()) == list(range(nrag)), what + ": the bucketing's order is not a permutation"
         for i in range(0, nrag, 7):
             m = rag["blob"][int(rag_offs[i]):int(rag_offs[i + 1])].tobytes()
