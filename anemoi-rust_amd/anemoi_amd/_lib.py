@@ -178,9 +178,9 @@ class ClockSampler:
         cs = ClockSampler(device); cs.start(work_stream); ...enqueue work...; cs.finish(work_stream); torch.cuda.synchronize()
         mean_ghz, min_ghz, max_ghz, groups = cs.read()"""
 
-    def __init__(self, device, period_us=2000, max_ms=120000):
+    def __init__(self, device, period_us=2000, max_ms=120000, wait_ms=1000):
         import torch
-        self.torch, self.period_us, self.max_ms = torch, period_us, max_ms
+        self.torch, self.period_us, self.max_ms, self.wait_ms = torch, period_us, max_ms, wait_ms
         self.bytes = lib.anemoi_clock_sampler_bytes()
         self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=device)
         self.stamps = torch.zeros(2, dtype=torch.int64, device=device)
@@ -189,7 +189,9 @@ class ClockSampler:
     def start(self, work_stream):
         self.side.wait_stream(self.torch.cuda.current_stream())     # (the buffers were zero-filled on the current stream)
         _check(lib.anemoi_clock_sampler_start_dev(self.buf.data_ptr(), self.bytes, self.period_us, self.max_ms, self.side.cuda_stream))
-        _check(lib.anemoi_clock_sampler_wait_dev(self.buf.data_ptr(), 50, work_stream.cuda_stream))   # the work starts once the sampler runs
+        # the work starts once the sampler runs: the wait ends with the sampler's first sample, so a generous bound costs
+        # nothing -- with 50 ms a sampler whose (new) stream took longer to start was seen to miss 100 ms of work entirely
+        _check(lib.anemoi_clock_sampler_wait_dev(self.buf.data_ptr(), self.wait_ms, work_stream.cuda_stream))
         _check(lib.anemoi_clock_stamp_dev(self.stamps.data_ptr(), work_stream.cuda_stream))
 
     def finish(self, work_stream):
@@ -210,6 +212,20 @@ class ClockSampler:
                                              ctypes.byref(v[1]), ctypes.byref(v[2]), ctypes.byref(g)))
         return v[0].value, v[1].value, v[2].value, g.value
 
+    def diagnose(self):
+        """why read() found no usable group: per sampler workgroup, how many samples it took and how many of them lie between
+        the caller's two stamps (layout of the log: csrc/capi.hip, SamplerBuf)"""
+        host = self.buf.cpu().numpy()
+        st = self.stamps.cpu().numpy().view(np.uint64)
+        out, off, per = [], 16, 8 + 4096 * 16
+        for i in range(16):
+            g = host[off + i * per: off + (i + 1) * per]
+            count = int(g[:4].view(np.uint32)[0])
+            wall = g[8:8 + 16 * min(count, 4096)].view(np.uint64)[0::2]
+            inside = int(((wall >= st[0]) & (wall <= st[1])).sum())
+            out.append((count, inside))
+        return {"stamps_ticks": (int(st[0]), int(st[1])), "work_ms": (int(st[1]) - int(st[0])) * 1e-5, "samples_taken_and_inside": out}
+
 
 def kernel_Mcycles(device, enqueue, reps=3, warmup=1, best=False):
     """The box-independent cost of a piece of device work: `enqueue(stream)` (one or more `_dev` calls) run `reps` times with
@@ -222,18 +238,22 @@ def kernel_Mcycles(device, enqueue, reps=3, warmup=1, best=False):
     for _ in range(warmup):
         enqueue(stream)
     torch.cuda.synchronize(device)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    cs = ClockSampler(device)
-    cs.start(stream)
-    for a, b in evs:
-        a.record(stream)
-        enqueue(stream)
-        b.record(stream)
-    cs.finish(stream)
-    torch.cuda.synchronize(device)
-    _, ghz_min, _, groups = cs.read()
-    if not groups or ghz_min <= 0:
-        raise RuntimeError("the clock sampler took no sample beside the work")
+    for attempt in (0, 1):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        cs = ClockSampler(device)
+        cs.start(stream)
+        for a, b in evs:
+            a.record(stream)
+            enqueue(stream)
+            b.record(stream)
+        cs.finish(stream)
+        torch.cuda.synchronize(device)
+        _, ghz_min, _, groups = cs.read()
+        if groups and ghz_min > 0:
+            break
+        kernel_Mcycles.last_miss = cs.diagnose()        # (kept for the caller: a measurement without its clock is repeated once)
+        if attempt:
+            raise RuntimeError("the clock sampler took no sample beside the work, twice: %r" % (kernel_Mcycles.last_miss,))
     each = [a.elapsed_time(b) for a, b in evs]
     ms = min(each) if best else sum(each) / reps
     kernel_Mcycles.last_each_ms = each
@@ -249,7 +269,7 @@ def release(device=ALL_DEVICES):
 
 OPTIONS = ("coop2d_max", "coop4_max", "coop43_max", "coop2d43_max", "coop_sponge_max", "coop_climb_max",
            "virtual_devices", "host_staging", "chunk_target_bytes", "test_quantum",
-           "sponge_segment_bytes")
+           "sponge_segment_bytes", "balance_underfilled")
 AUTO = -1
 
 

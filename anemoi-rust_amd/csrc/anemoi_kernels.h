@@ -229,15 +229,23 @@ ANEMOI_KERNEL void k_jive(const uint4* __restrict__ in, uint4* __restrict__ out,
 struct XcdAcct {
   unsigned long long blocks, first_start, last_end, wall_ticks, cycles;
 };
-struct AcctScope {
+struct AcctScope {   // (the start stamps wait in LDS: four more live SGPRs spilled k_jive_queue<bls12_381> to 169 VGPRs = 2 waves per SIMD)
   XcdAcct* a;
-  unsigned long long t0, c0;
-  __device__ __forceinline__ explicit AcctScope(XcdAcct* acct) : a(acct), t0(0), c0(0) {
-    if (a) t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+  __device__ __forceinline__ static unsigned long long* stamps() {
+    __shared__ unsigned long long st[2];
+    return st;
+  }
+  __device__ __forceinline__ explicit AcctScope(XcdAcct* acct) : a(acct) {
+    if (a && threadIdx.x == 0) {
+      unsigned long long* st = stamps();
+      st[0] = __builtin_amdgcn_s_memrealtime(), st[1] = __builtin_amdgcn_s_memtime();
+    }
   }
   __device__ __forceinline__ void end() {
     if (!a || threadIdx.x) return;
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long* st = stamps();
+    const unsigned long long t0 = st[0], c0 = st[1];
     XcdAcct& x = a[__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 7u];   // XCC_ID (as k_clock_sampler reads it)
     atomicAdd(&x.blocks, 1ull);
     atomicMin(&x.first_start, t0);
@@ -816,6 +824,24 @@ enum KernelKind { kKindPermutation = 0, kKindJive = 1, kKindSponge = 2, kKindCon
 
 const FieldOps* field_ops(int field);  // capi.hip
 
+// UNDERFILLED LAUNCHES GET A DO-NOTHING LAUNCH IN FRONT (round 6; tools/exp_cfg3_after_other_kernels.py, exp_balance_launch.py,
+// exp_balance_launch2.py; profiles/r06/underfilled_launch_placement.txt).  A launch whose single-wavefront workgroups all fit
+// the chip at once takes what its fullest SIMD takes, and the dispatcher does not place it evenly when it follows a launch that
+// OVER-filled the chip (16 384 workgroups of another kernel): it stacks three wavefronts on some SIMDs and leaves others with
+// one or none.  Measured, every time: config 3 (2 048 workgroups resident for 333 ms) 485 ms, x 1.46; 1 024 workgroups
+// x 1.84-1.89; 3 072 x 1.31; nothing at <= 512 workgroups or once the launch fills the chip itself.  Round 5 met the process's
+// first launch of it and cured that one with anemoi_warmup; the rule is wider -- a headline launch and config 3 alternating:
+// every config-3 launch slow.  What restores an even placement is ANY launch of <= 8 192 single-wavefront workgroups that
+// all retire together, in between -- 512 of them asleep for 20 us do, 25 us in all (16 384 do not, nor do 256-thread
+// workgroups; capping the workgroups per CU by their LDS request does not either: the imbalance is between the SIMDs of a
+// CU).  So every launch of 2 ... 16 workgroups per CU is preceded by k_balance: four workgroups per CU, ~20 us.  Only a
+// kernel launch on the caller's stream: capturable.  Option balance_underfilled = 0 switches it off (the A/B).
+void balance_launch(unsigned wgs, hipStream_t s);   // capi.hip: k_balance (one copy for the seven field translation units)
+inline void balance_before(size_t wgs, const PermConsts& pc, hipStream_t s) {
+  const size_t cus = size_t(pc.simds) / 4;
+  if (!cus || wgs <= 2 * cus || wgs >= 16 * cus || !opt::get_or(opt::kBalanceUnderfilled, 1)) return;
+  balance_launch(unsigned(4 * cus), s);
+}
 inline unsigned grid_for(size_t n) { return unsigned((n + kBlock - 1) / kBlock); }
 inline unsigned pair_grid(size_t n) { return unsigned((n + kBlock / 2 - 1) / (kBlock / 2)); }  // 32 states per workgroup
 
@@ -884,20 +910,26 @@ struct Launch {
     // latency path: the cut-offs of the Jive kernels (same permutation, same items per wavefront)
     if (!sbox_only && width == 2 && n <= coop2d_max_items(pc.simds)) {
       const size_t groups = (n + 1) / 2;
-      k_permutation_coop<FIELD, 2, 32><<<unsigned(groups < 65536 ? groups : 65536), kBlock, 0, s>>>((uint32_t*)d, n, pc);
+      const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      balance_before(g, pc, s);
+      k_permutation_coop<FIELD, 2, 32><<<g, kBlock, 0, s>>>((uint32_t*)d, n, pc);
       return hipGetLastError();
     }
     if (!sbox_only && width == 4 && n <= coop2d43_max_items(pc.simds)) {   // one 4-3 state per wavefront, a column per row pair
-      k_permutation_coop<FIELD, 4, 32><<<unsigned(n < 65536 ? n : 65536), kBlock, 0, s>>>((uint32_t*)d, n, pc);
+      const unsigned g = n < 65536 ? unsigned(n) : 65536u;
+      balance_before(g, pc, s);
+      k_permutation_coop<FIELD, 4, 32><<<g, kBlock, 0, s>>>((uint32_t*)d, n, pc);
       return hipGetLastError();
     }
     if (!sbox_only && n <= (width == 2 ? coop4_max_items(pc.simds) : coop43_max_items(pc.simds, F::Coop::NL))) {
       const size_t groups = width == 2 ? (n + 3) / 4 : (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      balance_before(g, pc, s);
       if (width == 2) k_permutation_coop<FIELD, 2><<<g, kBlock, 0, s>>>((uint32_t*)d, n, pc);
       else k_permutation_coop<FIELD, 4><<<g, kBlock, 0, s>>>((uint32_t*)d, n, pc);
       return hipGetLastError();
     }
+    balance_before(width == 2 ? grid_for(n) : pair_grid(n), pc, s);
     if (width == 2 && !sbox_only)
       k_permutation<FIELD, 2, false><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((uint4*)d, n, pc);
     else if (width == 2)
@@ -914,6 +946,7 @@ struct Launch {
 #if ANEMOI_AB_BUILD   // the recorded negative: one item per wavefront (four-row fold on 11 limbs, else rounds 1-2's scan)
     if (width == 2 && n <= coop_max_items()) {
       const unsigned g = n < 65536 ? unsigned(n) : 65536u;  // the kernel strides over items
+      balance_before(g, pc, s);
       k_jive2_coop<FIELD, 64><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
@@ -921,17 +954,20 @@ struct Launch {
     if (width == 2 && n <= coop2d_max_items(pc.simds)) {  // two items per wavefront on row pairs: the lowest latency
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      balance_before(g, pc, s);
       k_jive2_coop<FIELD, 32><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
     if (width == 2 && n <= coop4_max_items(pc.simds)) {  // four items per wavefront, one per DPP row
       const size_t groups = (n + 3) / 4;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      balance_before(g, pc, s);
       k_jive2_coop<FIELD, 16><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
     if (width == 4 && n <= coop2d43_max_items(pc.simds)) {  // 4-3, lowest latency: one state per wavefront on the two-row fold
       const unsigned g = n < 65536 ? unsigned(n) : 65536u;
+      balance_before(g, pc, s);
       if (k == 2) k_jive4_coop<FIELD, 2, 32><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       else k_jive4_coop<FIELD, 4, 32><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
@@ -939,10 +975,12 @@ struct Launch {
     if (width == 4 && n <= coop43_max_items(pc.simds, F::Coop::NL)) {  // 4-3 latency path: two states per wavefront
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      balance_before(g, pc, s);
       if (k == 2) k_jive4_coop<FIELD, 2><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       else k_jive4_coop<FIELD, 4><<<g, kBlock, 0, s>>>((const uint32_t*)in, (uint32_t*)out, n, pc);
       return hipGetLastError();
     }
+    balance_before(width == 2 ? grid_for(n) : pair_grid(n), pc, s);
     if (width == 2)
       k_jive<FIELD, 2, 2><<<grid_for(n), kBlock, lds_bytes<A, WIN, 2>(), s>>>((const uint4*)in, (uint4*)out, n, pc);
     else if (k == 2)
@@ -959,12 +997,14 @@ struct Launch {
     if (width == 2 && n <= coop2d_max_items(pc.simds)) {  // two messages per wavefront
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      balance_before(g, pc, s);
       if (bytes) k_sponge_coop<FIELD, 2, true, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
       else k_sponge_coop<FIELD, 2, false, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
       return hipGetLastError();
     }
     if (width == 4 && n <= coop2d43_max_items(pc.simds)) {  // one 4-3 message per wavefront
       const unsigned g = n < 65536 ? unsigned(n) : 65536u;
+      balance_before(g, pc, s);
       if (bytes) k_sponge_coop<FIELD, 4, true, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
       else k_sponge_coop<FIELD, 4, false, 32><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
       return hipGetLastError();
@@ -972,6 +1012,7 @@ struct Launch {
     if (n <= coop_sponge_max_items(pc.simds)) {  // four (2-1) / two (4-3) messages per wavefront on the scan
       const size_t groups = width == 2 ? (n + 3) / 4 : (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      balance_before(g, pc, s);
       if (width == 2 && bytes) k_sponge_coop<FIELD, 2, true><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
       else if (width == 2) k_sponge_coop<FIELD, 2, false><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
       else if (bytes) k_sponge_coop<FIELD, 4, true><<<g, kBlock, 0, s>>>(src, per_msg, n, (uint32_t*)out, pc, seg);
@@ -979,6 +1020,7 @@ struct Launch {
       return hipGetLastError();
     }
     const size_t l = lds_bytes<A, WIN, 1>(), lp = lds_bytes<A, WIN, 2>();
+    balance_before(width == 2 ? grid_for(n) : pair_grid(n), pc, s);
     if (width == 2 && bytes)
       k_sponge<FIELD, 2, true><<<grid_for(n), kBlock, l, s>>>(src, per_msg, n, (uint4*)out, pc, seg);
     else if (width == 2)
@@ -1011,20 +1053,26 @@ struct Launch {
     const uint32_t* st = (const uint32_t*)status;
     if (width == 2 && n <= coop2d_max_items(pc.simds)) {  // two messages per wavefront
       const size_t groups = (n + 1) / 2;
-      k_sponge_ragged_coop<FIELD, 2, BYTES, 32><<<unsigned(groups < 65536 ? groups : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord, st);
+      const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      balance_before(g, pc, s);
+      k_sponge_ragged_coop<FIELD, 2, BYTES, 32><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord, st);
       return hipGetLastError();
     }
     if (width == 4 && n <= coop2d43_max_items(pc.simds)) {  // one 4-3 message per wavefront
-      k_sponge_ragged_coop<FIELD, 4, BYTES, 32><<<unsigned(n < 65536 ? n : 65536), kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord, st);
+      const unsigned g = n < 65536 ? unsigned(n) : 65536u;
+      balance_before(g, pc, s);
+      k_sponge_ragged_coop<FIELD, 4, BYTES, 32><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord, st);
       return hipGetLastError();
     }
     if (n <= coop_sponge_max_items(pc.simds)) {  // four (2-1) / two (4-3) messages per wavefront on the scan
       const size_t groups = width == 2 ? (n + 3) / 4 : (n + 1) / 2;
       const unsigned g = unsigned(groups < 65536 ? groups : 65536);
+      balance_before(g, pc, s);
       if (width == 2) k_sponge_ragged_coop<FIELD, 2, BYTES, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord, st);
       else k_sponge_ragged_coop<FIELD, 4, BYTES, 16><<<g, kBlock, 0, s>>>(m, o, n, (uint32_t*)out, pc, ord, st);
       return hipGetLastError();
     }
+    balance_before(width == 2 ? grid_for(n) : pair_grid(n), pc, s);
     if (width == 2)
       k_sponge_ragged<FIELD, BYTES><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>(m, o, n, (uint4*)out, pc, ord, st);
     else
@@ -1044,6 +1092,7 @@ struct Launch {
     if (n <= coop2d_max_items(pc.simds)) {  // very few paths: two per wavefront on row pairs
       const size_t groups = (n + 1) / 2;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      balance_before(g, pc, s);
       k_merkle_climb_coop<FIELD, 32><<<g, kBlock, 0, s>>>((const uint32_t*)leaves, (const uint64_t*)index,
                                                            (const uint32_t*)paths, depth, n, (uint32_t*)out, pc);
       return hipGetLastError();
@@ -1051,10 +1100,12 @@ struct Launch {
     if (n <= coop_climb_max_items(pc.simds)) {  // a handful of paths: the latency form
       const size_t groups = (n + 3) / 4;
       const unsigned g = groups < 65536 ? unsigned(groups) : 65536u;
+      balance_before(g, pc, s);
       k_merkle_climb_coop<FIELD><<<g, kBlock, 0, s>>>((const uint32_t*)leaves, (const uint64_t*)index,
                                                        (const uint32_t*)paths, depth, n, (uint32_t*)out, pc);
       return hipGetLastError();
     }
+    balance_before(grid_for(n), pc, s);
     k_merkle_climb<FIELD><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>(
         (const uint4*)leaves, (const uint64_t*)index, (const uint4*)paths, depth, n, (uint4*)out, pc);
     return hipGetLastError();
@@ -1062,6 +1113,7 @@ struct Launch {
 
   static hipError_t generic_permutation(void* d, size_t n, GenericConsts gc, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
+    balance_before(cols_grid(n, gc.cols), pc, s);
     k_permutation_cols<FIELD><<<cols_grid(n, gc.cols), kBlock, lds_bytes<A, WIN, 1>(), s>>>((uint32_t*)d, n, gc, pc);
     return hipGetLastError();
   }
@@ -1069,6 +1121,7 @@ struct Launch {
   static hipError_t generic_jive(const void* in, void* out, size_t n, int k, GenericConsts gc, PermConsts pc,
                                  hipStream_t s) {
     if (!n) return hipSuccess;
+    balance_before(cols_grid(n, gc.cols), pc, s);
     k_jive_cols<FIELD><<<cols_grid(n, gc.cols), kBlock, lds_bytes<A, WIN, 1>(), s>>>((const uint32_t*)in, (uint32_t*)out,
                                                                                       n, k, gc, pc);
     return hipGetLastError();
@@ -1078,6 +1131,7 @@ struct Launch {
                                    GenericConsts gc, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
     const unsigned g = cols_grid(n, gc.cols);
+    balance_before(g, pc, s);
     if (bytes)
       k_sponge_cols<FIELD, true><<<g, kBlock, lds_bytes<A, WIN, 1>(), s>>>(src, per_msg, n, (uint32_t*)out, rate, gc, pc);
     else
@@ -1087,6 +1141,7 @@ struct Launch {
 
   static hipError_t exp_alpha(int inverse, void* d, size_t n, PermConsts pc, hipStream_t s) {
     if (!n) return hipSuccess;
+    balance_before(grid_for(n), pc, s);
     if (inverse) k_exp_alpha<FIELD, true><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>((uint4*)d, n, pc);
     else k_exp_alpha<FIELD, false><<<grid_for(n), kBlock, lds_bytes<A, WIN, 1>(), s>>>((uint4*)d, n, pc);
     return hipGetLastError();

@@ -522,6 +522,17 @@ __global__ void k_ragged_place(const uint64_t* __restrict__ off, size_t n, uint3
   if (i < n) order[atomicAdd(&bins[ragged_bin(off, i, block_units)], 1u)] = uint32_t(i);
 }
 
+// The do-nothing launch in front of a launch that does not fill the chip (anemoi_kernels.h: balance_before): single-wavefront
+// workgroups asleep for ~20 us, which all retire together.
+__global__ void k_balance(unsigned sleeps) {
+  for (unsigned i = 0; i < sleeps; i++) __builtin_amdgcn_s_sleep(127);   // 127 x 64 clocks ~ 3.4 us
+}
+}  // namespace
+namespace anemoi {
+void balance_launch(unsigned wgs, hipStream_t s) { k_balance<<<wgs, 64, 0, s>>>(6); }
+}  // namespace anemoi
+namespace {
+
 // anemoi_probe_issue_rate: every lane runs ONE dependent chain of v_mad_u64_u32 -- the instruction that carries the
 // throughput kernels (75 % of their instructions) -- with the register footprint of those kernels (161 VGPRs claimed:
 // three wavefronts per SIMD, launched as exactly three per SIMD), and stamps the shader clock (s_memtime) and the
@@ -1165,6 +1176,17 @@ static int x_jive_queue(int field, const void* d_in, void* d_out, size_t n, void
 int anemoi_x_jive_queue_dev(int field, const void* d_in, void* d_out, size_t n, void* d_queue, unsigned wgs, void* stream) {
   if (!wgs) return ANEMOI_ERR_ARG;
   return x_jive_queue(field, d_in, d_out, n, d_queue, wgs, nullptr, stream);
+}
+// EXPERIMENT (tools/exp_balance_launch.py): a launch that does nothing but occupy wave slots for `sleeps` x ~3.4 us, in front of
+// an underfilled launch that follows a different kernel -- does it change where the dispatcher puts the next launch's waves?
+__global__ void k_x_balance(unsigned sleeps) {
+  for (unsigned i = 0; i < sleeps; i++) __builtin_amdgcn_s_sleep(127);
+}
+int anemoi_x_balance_dev(unsigned wgs, unsigned threads, unsigned sleeps, void* stream) {
+  if (!wgs || !threads || threads > 1024) return ANEMOI_ERR_ARG;
+  k_x_balance<<<wgs, threads, 0, (hipStream_t)stream>>>(sleeps);
+  HIP_TRY(hipGetLastError());
+  return ANEMOI_OK;
 }
 // ... and with the per-XCD accounting (anemoi_kernels.h: XcdAcct; d_acct = 8 records of 5 uint64, prepared by the caller):
 // wgs = 0 is the SHIPPED static dealing, wgs < blocks the queue, wgs >= blocks the tickets

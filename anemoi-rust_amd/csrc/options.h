@@ -34,6 +34,7 @@ enum Id {
   kSpongeSegmentBytes,  // forces the segment-fed sponge with this many bytes per segment (auto: by batch shape)
   kVirtualDevices,      // ANEMOI_ALL_DEVICES cuts into this many parts (auto: the GPU count)
   kHostStaging,         // 1 = stage host buffers through pinned memory (auto), 0 = copy straight from / to the caller's memory
+  kBalanceUnderfilled,  // 1 (auto) = a launch of 2 ... 16 workgroups per CU is preceded by a do-nothing launch (k_balance: even placement)
   kCount
 };
 
@@ -59,6 +60,7 @@ inline const Spec& spec(int id) {
       {"sponge_segment_bytes", "ANEMOI_SPONGE_SEGMENT_BYTES", 1, 1ll << 40},
       {"virtual_devices", "ANEMOI_VIRTUAL_DEVICES", 1, 64},
       {"host_staging", "ANEMOI_HOST_STAGING", 0, 1},
+      {"balance_underfilled", "ANEMOI_BALANCE_UNDERFILLED", 0, 1},
   };
   return table[id];
 }

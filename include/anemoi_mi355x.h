@@ -125,7 +125,9 @@ int anemoi_release(int device);
  * wavefronts unevenly over the SIMDs of a CU (three on one, one on another); a launch whose workgroups all start at
  * once and stay for its whole duration -- 2^16 long messages: 2 048 wavefronts for a third of a second -- then takes
  * x 1.5 (profiles/r05/).  A service that cares about its FIRST large call calls this at start-up;
- * it waits for its launches, so it is not for capture either. */
+ * it waits for its launches, so it is not for capture either.  (Since round 6 the library itself precedes every launch that
+ * does not fill the chip by a do-nothing launch that restores an even placement -- option balance_underfilled -- which covers
+ * the first call as well; anemoi_warmup still takes the constant upload and the code-object load out of that call.) */
 int anemoi_warmup(int device, int field, int width);
 
 /* ---- diagnostics ----------------------------------------------------------------------------
@@ -192,6 +194,12 @@ int anemoi_clock_sampler_read(const void *h_buf, size_t bytes, unsigned long lon
  *   chunk_target_bytes     ANEMOI_CHUNK_TARGET_BYTES    24 MiB                         input bytes per chunk of the host pipelines (test knob)
  *   test_quantum           ANEMOI_TEST_QUANTUM          occupancy API                  items per full wave of workgroups (test knob)
  *   sponge_segment_bytes   ANEMOI_SPONGE_SEGMENT_BYTES  by batch shape                 forces the segment-fed sponge, this many bytes per segment
+ *   balance_underfilled    ANEMOI_BALANCE_UNDERFILLED   1                              1: a launch of 2 ... 16 single-wavefront workgroups per CU (one
+ *                                                                                      that does not fill the chip) is preceded by a do-nothing launch
+ *                                                                                      of 4 workgroups per CU (~25 us): without it such a launch takes
+ *                                                                                      x 1.3 ... 1.9 whenever it follows a launch that over-filled the
+ *                                                                                      chip -- the dispatcher stacks its wavefronts on some SIMDs
+ *                                                                                      (profiles/r06/underfilled_launch_placement.txt); 0: off (A/B)
  */
 int anemoi_set_option(const char *name, long long value);
 int anemoi_get_option(const char *name, long long *value); /* the value in force; -1 = automatic */

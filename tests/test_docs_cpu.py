@@ -70,3 +70,87 @@ def test_quoted_counts_are_the_headers():
     assert "anemoi_abi_version(void) { return 100 * ANEMOI_ABI_MAJOR + ANEMOI_ABI_MINOR; }" in src
     # ... and the header's own count of its functions, in the rule's history line
     assert ("(%d functions)" % n) in raw
+
+
+# ---------------------------------------------------------------- committed profile summaries regenerate, and say what the documents say
+
+def _profile_rounds():
+    return sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d\d", d))
+
+
+def _newest(name):
+    for r in reversed(_profile_rounds()):
+        p = os.path.join(ROOT, "profiles", r, name)
+        if os.path.exists(p):
+            return r, p
+    raise AssertionError("no profiles/rNN/%s" % name)
+
+
+def test_config_profile_summaries_are_sane():
+    """Round 5's review, weak item 4: profiles/r04 and r05/pmc_configs.json said "config 3 = 1.91 ms, 166 x the flat rate" for
+    two rounds (the summariser picked the profile tool's own small warm-up launch of the same kernel).  Every committed
+    pmc_configs.json that carries the per-row `grid` (r04 on) must hold figures that can be true."""
+    import json
+    seen = 0
+    for r in _profile_rounds():
+        p = os.path.join(ROOT, "profiles", r, "pmc_configs.json")
+        if not os.path.exists(p):
+            continue
+        d = json.load(open(p))
+        s = d["summary"]
+        if "cfg5_fraction_of_flat_rate" not in s:
+            continue                                   # r03: the older layout, superseded
+        seen += 1
+        assert 0.85 < s["cfg3_fraction_of_flat_rate"] <= 1.02, (r, s["cfg3_fraction_of_flat_rate"])
+        assert 250.0 < s["cfg3_ms"] < 450.0, (r, s["cfg3_ms"])
+        assert 0.6 < s["cfg5_fraction_of_flat_rate"] <= 1.0, (r, s["cfg5_fraction_of_flat_rate"])
+        assert 60.0 < s["cfg5_sum_of_levels_ms"] < 120.0, (r, s["cfg5_sum_of_levels_ms"])
+        assert 25.0 < s["flat_jubjub_2_1_M_per_s"] < 40.0 and 18.0 < s["flat_bn254_4_3_M_per_s"] < 30.0, r
+        cfg3 = [k for k in d["kernels"] if k["kernel"].startswith("k_sponge_pair<2, true>") and k["grid"] == 131072]
+        assert len(cfg3) == 1 and abs(cfg3[0]["kernel_ms_min_stats_pass"] - s["cfg3_ms"]) < 1e-3, r   # the CONFIG's dispatch: 2^16 messages
+        for k in d["kernels"]:
+            t = k["traffic_over_algorithmic"]
+            assert t is None or 0.95 < t < 400.0, (r, k["kernel"], k["grid"], t)          # (a lone wavefront reads 44 KB of constants for 192 bytes)
+            if t is not None and k["wavefronts"] >= 2048:
+                assert t < 1.5, (r, k["kernel"], k["grid"], t)                             # a full launch wastes nothing
+            assert 0.5 < k["kernel_ms_min_stats_pass"] < 500.0 and 1.5 < k["clock_GHz"] < 2.6, (r, k["kernel"], k["grid"])
+    assert seen >= 2
+
+
+def test_design_quotes_the_newest_profiles():
+    """DESIGN.md section 5 quotes config 3 / config 5 / the headline from the newest round's committed files, in sentences
+    this test can read; a figure that drifts from its file fails here."""
+    import json
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    r, p = _newest("pmc_configs.json")
+    s = json.load(open(p))["summary"]
+    m = re.search(r"`profiles/(r\d\d)/pmc_configs\.json`: config 3 (\d+\.\d) ms = (0\.\d+) of the flat rate; config 5 (\d+\.\d) ms as the sum of its "
+                  r"levels = (0\.\d+) of the flat rate", text)
+    assert m, "DESIGN.md does not quote profiles/%s/pmc_configs.json in the agreed sentence" % r
+    assert m.group(1) == r, "DESIGN.md quotes %s, the newest summary is %s" % (m.group(1), r)
+    assert abs(float(m.group(2)) - s["cfg3_ms"]) < 0.06 and abs(float(m.group(3)) - s["cfg3_fraction_of_flat_rate"]) < 0.0006
+    assert abs(float(m.group(4)) - s["cfg5_sum_of_levels_ms"]) < 0.06 and abs(float(m.group(5)) - s["cfg5_fraction_of_flat_rate"]) < 0.0006
+    r, p = _newest("bench_n1.json")
+    line = json.loads([l for l in open(p).read().splitlines() if l.startswith("{")][-1])
+    m = re.search(r"`profiles/(r\d\d)/bench_n1\.json`: (\d+\.\d\d) M/s, (\d+\.\d) ms per 2\^20 batch, (\d+\.\d) Mcycles", text)
+    assert m and m.group(1) == r, "DESIGN.md does not quote profiles/%s/bench_n1.json in the agreed sentence" % r
+    assert abs(float(m.group(2)) - line["value"] / 1e6) < 0.006
+    assert abs(float(m.group(3)) - line["ms_per_step"]) < 0.06
+    assert abs(float(m.group(4)) - line["alu"]["kernel_Mcycles_slowest_xcd"]) < 0.06
+
+
+def test_design_quotes_the_collected_test_counts():
+    """DESIGN.md section 4 says how many tests each suite holds: compared with what pytest collects (round 5 said 308 where
+    the driver collected 309)."""
+    import subprocess
+    import sys
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for marker, pat in (("gpu", r"`pytest -m gpu` \((\d+) tests"), ("not gpu", r"`-m \"not gpu\"` \((\d+) tests")):
+        out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "--collect-only", "-q", "-m", marker],
+                             capture_output=True, text=True, timeout=600, cwd=ROOT).stdout
+        m = re.search(r"(\d+)/\d+ tests collected|(\d+) tests collected", out)
+        assert m, out[-500:]
+        n = int(m.group(1) or m.group(2))
+        q = re.search(pat, text)
+        assert q, "DESIGN.md section 4 does not state the %r count in the agreed form" % marker
+        assert int(q.group(1)) == n, "DESIGN.md says %s %r tests, pytest collects %d" % (q.group(1), marker, n)
