@@ -561,6 +561,59 @@ def test_malformed_device_offsets_are_reported_not_followed(A, oracle):
                 assert (got[keep] == want[keep]).all(), (field, width, n, unit)
 
 
+def test_underfilled_launch_is_placed_evenly_whatever_ran_before(A, synth):
+    """Round 6 (profiles/r06/underfilled_launch_placement.txt): a launch whose single-wavefront workgroups all fit the chip at
+    once took x 1.3 ... 1.9 whenever it followed a launch that over-filled the chip -- config 3 485 instead of 333 ms, every
+    time -- because the dispatcher then stacks three wavefronts on some SIMDs.  The library now puts a do-nothing launch in
+    front of such launches (option balance_underfilled).  Here: 1 024 and 2 048 workgroups of the BLS12-381 Jive kernel and of
+    the BN-254 4-3 sponge kernel, each launched right after a 2^20 Jubjub Jive batch (the disturbing launch), must take what
+    they take after themselves (+ 12 %); the same with the option off is printed beside it (x 1.46-1.9 on every box so far --
+    hardware behaviour, not asserted)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream()
+    rng = np.random.default_rng(77)
+    mlen, n = 2048, 1 << 20
+    msgs = torch.from_numpy(rng.integers(0, 256, size=(2048 * 32, mlen), dtype=np.uint8)).to(dev)
+    dig = torch.empty(2048 * 32 * 4, dtype=torch.int64, device=dev)
+    bn, bls, jub = FIELD_IDS.index("bn_254"), FIELD_IDS.index("bls12_381"), FIELD_IDS.index("jubjub")
+    d_bls = torch.from_numpy(synth.states("bls12_381", 2, 5, 0, 2048 * 64).view(np.int64).reshape(-1)).to(dev)
+    d_jub = torch.from_numpy(synth.states("jubjub", 2, 6, 0, n).view(np.int64).reshape(-1)).to(dev)
+    o_bls = torch.empty(2048 * 64 * 6, dtype=torch.int64, device=dev)
+    o_jub = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    for f, w in ((bn, 4), (bls, 2), (jub, 2)):
+        assert A.lib.anemoi_init(0, f, w) == 0
+
+    def timed(fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        assert fn() == 0
+        b.record(st)
+        torch.cuda.synchronize()
+        return a.elapsed_time(b)
+
+    lane_private = dict(coop2d_max=0, coop4_max=0, coop43_max=0, coop2d43_max=0, coop_sponge_max=0)
+    sponge = lambda wgs: timed(lambda: A.lib.anemoi_hash_bytes_dev(bn, 4, msgs.data_ptr(), mlen, wgs * 32, dig.data_ptr(), st.cuda_stream))
+    jive = lambda wgs: timed(lambda: A.lib.anemoi_jive_compress_k_dev(bls, 2, 2, d_bls.data_ptr(), o_bls.data_ptr(), wgs * 64, st.cuda_stream))
+    disturb = lambda: timed(lambda: A.lib.anemoi_jive_compress_k_dev(jub, 2, 2, d_jub.data_ptr(), o_jub.data_ptr(), n, st.cuda_stream))
+    with knobs(**lane_private):
+        for name, target in (("sponge bn_254 4-3", sponge), ("jive bls12_381 2-1", jive)):
+            for wgs in (1024, 2048):
+                target(wgs)
+                steady = min(target(wgs) for _ in range(3))
+                ratios = {}
+                for on in (1, 0):
+                    with knobs(balance_underfilled=on):
+                        worst = 0.0
+                        for _ in range(2):
+                            disturb()
+                            worst = max(worst, target(wgs))
+                        ratios[on] = worst / steady
+                print("%s, %d workgroups: %.2f ms after itself; after a 2^20 launch of another kernel x %.2f (balanced), x %.2f (option off)"
+                      % (name, wgs, steady, ratios[1], ratios[0]))
+                assert ratios[1] < 1.12, (name, wgs, steady, ratios)
+
+
 def test_pinned_caller_buffers_are_used_directly(A, oracle):
     """Host buffers that are already pinned (here: pinned torch tensors) skip the staging copy; results are the
     same bits, also when only one side is pinned and across several chunks."""
