@@ -32,6 +32,14 @@ use ark_ff::Zero;
 /// Batches smaller than this run on the CPU through the reference's own functions.
 pub const MI355X_MIN_BATCH: usize = 32;
 
+/// The header's ABI-version rule (include/anemoi_mi355x.h): the library answers 100 x major + minor of the header IT was built
+/// from; this crate, generated from a header of (ANEMOI_ABI_MAJOR, ANEMOI_ABI_MINOR), may use a library of the same major and
+/// the same or a later minor, and nothing else.
+pub fn mi355x_abi_compatible() -> bool {
+    let v = unsafe { ffi::anemoi_abi_version() };
+    v / 100 == ffi::ANEMOI_ABI_MAJOR && v % 100 >= ffi::ANEMOI_ABI_MINOR
+}
+
 /// The library never aborts: its error codes become the panics the reference raises itself.
 #[inline]
 fn check(rc: core::ffi::c_int) {
@@ -60,6 +68,7 @@ macro_rules! impl_mi355x {
                 /// instance's constant tables to every GPU and runs each of its throughput kernels once on a small batch
                 /// (~15 ms per GPU; include/anemoi_mi355x.h anemoi_warmup).  Changes no result.
                 pub fn mi355x_warmup() {
+                    assert!(mi355x_abi_compatible(), "libanemoi_mi355x.so has another ABI major than this crate was generated for");
                     check(unsafe { ffi::anemoi_warmup(ffi::ANEMOI_ALL_DEVICES, $field_id, $width) });
                 }
 
