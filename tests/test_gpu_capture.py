@@ -118,6 +118,22 @@ def test_dev_calls_captured_into_a_graph_and_replayed(oracle, params):
     d_root.zero_(), d_dig.zero_(), d_out.zero_(), d_rag_out.zero_(), fresh_ragged()
     graph.replay()
     check("replay after the options were restored")
+    # round 6: the offsets are captured DATA -- corrupt them in device memory (a pair that decreases), replay: the status word
+    # says so, the ragged digests are zero, nothing faulted and the graph's other work is right; restore them, replay: the
+    # word is 0 again (a kernel of the graph zeroes it on every replay) and the digests are the messages' own
+    bad = rag_offs.copy()
+    bad[nrag // 3 + 1] = np.uint64(1) << np.uint64(63)               # (the NEXT pair decreases; followed, it would read 2^63 bytes)
+    d_rag_offs.copy_(torch.from_numpy(bad.view(np.int64)).to(dev))
+    d_rag_out.fill_(-1)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert d_rag_scr[:4].cpu().numpy().view(np.uint32)[0] == 1, "a decreasing pair under replay: status word"
+    assert not d_rag_out.cpu().numpy().any(), "malformed offsets under replay: zero digests"
+    assert (d_root.cpu().numpy().view(np.uint64) == oracle.merkle_root(jub, leaves, depth)).all()
+    d_rag_offs.copy_(torch.from_numpy(rag_offs.view(np.int64)).to(dev))
+    d_root.zero_(), d_dig.zero_(), d_out.zero_(), d_rag_out.zero_(), fresh_ragged()
+    graph.replay()
+    check("replay after the offsets were repaired")
 
 
 def test_every_other_dev_entry_point_replays_like_a_direct_call(oracle, params):
