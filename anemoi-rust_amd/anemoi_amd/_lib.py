@@ -178,13 +178,38 @@ class ClockSampler:
         cs = ClockSampler(device); cs.start(work_stream); ...enqueue work...; cs.finish(work_stream); torch.cuda.synchronize()
         mean_ghz, min_ghz, max_ghz, groups = cs.read()"""
 
-    def __init__(self, device, period_us=2000, max_ms=120000, wait_ms=1000):
+    def __init__(self, device, period_us=2000, max_ms=120000, wait_ms=1000, stream_priorities="auto"):
         import torch
         self.torch, self.period_us, self.max_ms, self.wait_ms = torch, period_us, max_ms, wait_ms
         self.bytes = lib.anemoi_clock_sampler_bytes()
         self.buf = torch.zeros(self.bytes, dtype=torch.uint8, device=device)
         self.stamps = torch.zeros(2, dtype=torch.int64, device=device)
-        self.side, self.third = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        # The sampler never ends by itself, so its stream must not share a HARDWARE QUEUE with the work's stream: HIP
+        # multiplexes the streams of one priority onto GPU_MAX_HW_QUEUES (4) queues, round-robin in the order they are
+        # created, and runs the kernels of streams that share a queue one after the other -- the work then waits until the
+        # sampler's log is full (4 096 periods: 0.4 ... 8 s) and runs without a sampler (round 6: "no sample beside the
+        # work" in some test orders; tools/exp_sampler_queue_collision.py: every fourth sampler when each takes ONE
+        # default-priority stream).  Streams of different priorities never share a queue, and this platform has two
+        # (torch.cuda.Stream.priority_range() = (0, -1)): the sampler runs on a HIGH-priority stream -- it sleeps, so its
+        # priority costs the work nothing -- and its stop on a default-priority one (which may share a queue with the
+        # work: it is ordered behind the work anyway).  The work (the caller's stream) is assumed to have the default
+        # priority.  stream_priorities=None: two default-priority streams, as round 5 did (the A/B).
+        if stream_priorities is None:
+            self.side, self.third = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        else:
+            lo, hi = self.priority_range()
+            side_p, third_p = (hi, lo) if stream_priorities == "auto" else stream_priorities
+            self.side, self.third = torch.cuda.Stream(device, priority=side_p), torch.cuda.Stream(device, priority=third_p)
+
+    @staticmethod
+    def priority_range():
+        """(lowest, highest) stream priority of the device as torch numbers them (a smaller number is a higher priority)"""
+        import torch
+        try:
+            least, greatest = torch.cuda.Stream.priority_range()
+        except Exception:   # noqa: BLE001  (older torch: -1 = high, 0 = default)
+            least, greatest = 0, -1
+        return least, greatest
 
     def start(self, work_stream):
         self.side.wait_stream(self.torch.cuda.current_stream())     # (the buffers were zero-filled on the current stream)

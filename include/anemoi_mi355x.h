@@ -156,7 +156,13 @@ int anemoi_probe_issue_rate(int device, double *lane_mad_per_s, double *shader_c
  *     anemoi_clock_sampler_read(host_buf, bytes, stamps[0], stamps[1], &mean, &lo, &hi, &groups);
  * (period_us 10 ... 1 000 000, max_ms 1 ... 600 000, else ANEMOI_ERR_ARG.)
  * The sampler ends when stopped, when its log (4 096 samples) is full, or after max_ms, whichever comes first.  The stop
- * must be issued on a stream that does not wait for the sampler.  anemoi_clock_sampler_wait_dev holds `stream` (a one-lane
+ * must be issued on a stream that does not wait for the sampler.  NEITHER may the work's or the stop's stream share a HARDWARE
+ * QUEUE with the sampler's: HIP multiplexes the streams of one priority onto GPU_MAX_HW_QUEUES (4) queues, round-robin in
+ * the order they are created, and runs the kernels of streams that share a queue one after the other -- the work would wait
+ * until the sampler's log is full (4 096 periods) and then run without a sampler.  Streams of different priorities never
+ * share a queue: create side_stream with hipStreamCreateWithPriority(.., hipStreamNonBlocking, <greatest priority>) -- the
+ * sampler sleeps, its priority costs the work nothing -- and keep the work and the stop on default-priority streams
+ * (profiles/r06/sampler_queue_collision.txt; anemoi_amd.ClockSampler does this).  anemoi_clock_sampler_wait_dev holds `stream` (a one-lane
  * kernel, at most timeout_ms = 1 ... 10 000) until the sampler has taken its first sample: a sampler whose stream is slow
  * to start would otherwise miss a short piece of work.  bench.py reports the clock of its timed steps this way. */
 size_t anemoi_clock_sampler_bytes(void);
