@@ -294,7 +294,7 @@ def release(device=ALL_DEVICES):
 
 OPTIONS = ("coop2d_max", "coop4_max", "coop43_max", "coop2d43_max", "coop_sponge_max", "coop_climb_max",
            "virtual_devices", "host_staging", "chunk_target_bytes", "test_quantum",
-           "sponge_segment_bytes", "balance_underfilled")
+           "sponge_segment_bytes", "balance_underfilled", "lane_priorities")
 AUTO = -1
 
 

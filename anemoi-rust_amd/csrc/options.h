@@ -35,6 +35,7 @@ enum Id {
   kVirtualDevices,      // ANEMOI_ALL_DEVICES cuts into this many parts (auto: the GPU count)
   kHostStaging,         // 1 = stage host buffers through pinned memory (auto), 0 = copy straight from / to the caller's memory
   kBalanceUnderfilled,  // 1 (auto) = a launch of 2 ... 16 workgroups per CU is preceded by a do-nothing launch (k_balance: even placement)
+  kLanePriorities,      // 1 (auto) = every second lane's kernel stream is a high-priority stream (its own set of hardware queues)
   kCount
 };
 
@@ -61,6 +62,7 @@ inline const Spec& spec(int id) {
       {"virtual_devices", "ANEMOI_VIRTUAL_DEVICES", 1, 64},
       {"host_staging", "ANEMOI_HOST_STAGING", 0, 1},
       {"balance_underfilled", "ANEMOI_BALANCE_UNDERFILLED", 0, 1},
+      {"lane_priorities", "ANEMOI_LANE_PRIORITIES", 0, 1},
   };
   return table[id];
 }

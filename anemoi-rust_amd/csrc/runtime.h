@@ -102,6 +102,7 @@ struct Lane {
   // workgroups fill the CUs as the previous chunk drains (one stream would put a full barrier -- ~1.3 ms
   // of ragged tail on a 19 ms chunk, measured -- between every two chunks).
   hipStream_t s_k = nullptr, s_k2 = nullptr, s_in = nullptr, s_out = nullptr;
+  bool high_priority = false;
   Slot slot[kSlots];
   Buf scratch[kScratch];
   std::vector<hipEvent_t> events;  // extra events (one per tree level), created on demand
@@ -118,7 +119,19 @@ struct Lane {
 
   int create(int device) {
     dev = device;
-    HIP_TRY(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking));
+    // HIP keeps a separate set of hardware queues per stream PRIORITY (streams of different priorities never share a queue:
+    // profiles/r06/sampler_queue_collision.txt), and this platform has two.  Every second lane takes the other one, so
+    // that concurrent callers spread over twice the queues without GPU_MAX_HW_QUEUES in the host's environment
+    // (option lane_priorities; tools/exp_lane_priorities.py).
+    static std::atomic<unsigned> made{0};
+    int least = 0, greatest = 0;
+    if (anemoi::opt::get_or(anemoi::opt::kLanePriorities, 1) && (made.fetch_add(1) & 1u) &&
+        hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+      HIP_TRY(hipStreamCreateWithPriority(&s_k, hipStreamNonBlocking, greatest));
+      high_priority = true;
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking));
+    }
     for (auto& s : slot) {
       s.p_in.pinned = s.p_out.pinned = true;
       HIP_TRY(hipEventCreateWithFlags(&s.e_in, hipEventDisableTiming));
@@ -130,7 +143,14 @@ struct Lane {
   int pipeline_streams() {  // the three extra streams of the multi-chunk pipeline, on first need
     if (!s_in) HIP_TRY(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
     if (!s_out) HIP_TRY(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
-    if (!s_k2) HIP_TRY(hipStreamCreateWithFlags(&s_k2, hipStreamNonBlocking));
+    if (!s_k2) {   // the OTHER priority than s_k: the two kernel streams of a lane can then never share a hardware queue
+      int least = 0, greatest = 0;
+      if (anemoi::opt::get_or(anemoi::opt::kLanePriorities, 1) && !high_priority &&
+          hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        HIP_TRY(hipStreamCreateWithPriority(&s_k2, hipStreamNonBlocking, greatest));
+      else
+        HIP_TRY(hipStreamCreateWithFlags(&s_k2, hipStreamNonBlocking));
+    }
     return ANEMOI_OK;
   }
   void destroy() {

@@ -206,6 +206,10 @@ int anemoi_clock_sampler_read(const void *h_buf, size_t bytes, unsigned long lon
  *                                                                                      x 1.3 ... 1.9 whenever it follows a launch that over-filled the
  *                                                                                      chip -- the dispatcher stacks its wavefronts on some SIMDs
  *                                                                                      (profiles/r06/underfilled_launch_placement.txt); 0: off (A/B)
+ *   lane_priorities        ANEMOI_LANE_PRIORITIES       1                              1: every second lane's kernel stream (and the second kernel stream
+ *                                                                                      of every lane's chunked pipeline) is a HIGH-priority stream: HIP keeps
+ *                                                                                      a set of hardware queues per priority, so concurrent callers spread
+ *                                                                                      over twice the queues (read when a lane is created); 0: round 5
  */
 int anemoi_set_option(const char *name, long long value);
 int anemoi_get_option(const char *name, long long *value); /* the value in force; -1 = automatic */
