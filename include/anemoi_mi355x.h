@@ -367,7 +367,8 @@ int anemoi_hash_bytes_ragged_dev(int field, int width, const void *d_msgs, const
  * the FIRST 32-BIT WORD OF d_scratch -- ANEMOI_RAGGED_DECREASING if some offsets[i+1] < offsets[i], ANEMOI_RAGGED_BEYOND_EXTENT
  * if offsets[n] > msgs_len -- and the sponge launch, seeing the word set, writes n all-zero digests and reads no byte of
  * d_msgs.  The function itself returns ANEMOI_OK (it only enqueues); the caller reads the word once the work on `stream`
- * has completed (hipMemcpyAsync of 4 bytes behind the call): 0 = every digest is valid.  With non-decreasing offsets and
+ * has completed (hipMemcpyAsync of 4 bytes behind the call): 0 = every digest is valid (n = 0 enqueues nothing and leaves
+ * the word as it is).  With non-decreasing offsets and
  * offsets[n] <= msgs_len every read lies inside d_msgs, so no device-resident value can make this call fault. */
 #define ANEMOI_RAGGED_DECREASING 1
 #define ANEMOI_RAGGED_BEYOND_EXTENT 2

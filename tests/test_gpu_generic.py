@@ -131,6 +131,46 @@ def test_matrix_arm_vs_oracle(A, R, oracle, field, cols):
         assert (g1.permutation_batch(st) == g2.permutation_batch(st)).all()
 
 
+@pytest.mark.parametrize("field", ["bls12_377", "ed_on_bls12_377", "jubjub", "pallas"])
+@pytest.mark.parametrize("cols,matrix", [(1, None), (2, "builtin"), (3, None), (5, "random")])
+def test_unreduced_states_and_constants_are_taken_mod_p(A, R, oracle, field, cols, matrix):
+    """The input contract of round 6 (header: UNREDUCED INPUTS) on the run-time-instance entry points: states, messages AND the
+    instance's constants (ARK_C, ARK_D, the matrix) given as X + k p, up to the top of the 64 L-bit range, must give what the
+    reduced values give -- permutation, Jive, hash_field; host forms and a prepared instance on device pointers."""
+    import torch
+    fid = FIELD_IDS.index(field)
+    base = R.Instance(field, 2)
+    p, L = base.p, base.limbs
+    room = ((1 << (64 * L)) - 1) // p                      # X + k p fits for k < room (2 on jubjub ... 152 on bls12_377)
+    rng = random.Random(17 * cols + fid)
+    lift = lambda a: A.ints_to_limbs([v + rng.randrange(1, room) * p for v in A.limbs_to_ints(a)], L).reshape(np.shape(a))
+    rounds = 3
+    C = [rng.randrange(p) for _ in range(cols * rounds)]
+    D = [rng.randrange(p) for _ in range(cols * rounds)]
+    M = None if matrix is None else ([rng.randrange(p) for _ in range(cols * cols)] if matrix == "random" else R.builtin_mds_matrix(cols, base.g, p))
+    enc = lambda v: oracle.ints_to_mont(fid, [int(x) for x in v])
+    g_red = A.GenericAnemoi(field, cols, rounds, enc(C), enc(D), None if M is None else enc(M))
+    g_raw = A.GenericAnemoi(field, cols, rounds, lift(enc(C)), lift(enc(D)), None if M is None else lift(enc(M)))
+    w = 2 * cols
+    st = np.stack([enc([rng.randrange(p) for _ in range(w)]) for _ in range(70)])
+    raw = lift(st)
+    assert (raw != st).any()
+    want = g_red.permutation_batch(st)
+    assert (g_raw.permutation_batch(raw) == want).all() and (g_red.permutation_batch(raw) == want).all()
+    assert (g_raw.compress_k_batch(raw, 2) == g_red.compress_k_batch(st, 2)).all()
+    rate = w - 1
+    msgs = np.stack([enc([rng.randrange(p) for _ in range(2 * rate + 1)]) for _ in range(9)])
+    assert (g_raw.hash_field_batch(lift(msgs), rate) == g_red.hash_field_batch(msgs, rate)).all()
+    for inverse in (False, True):                          # exp_by_alpha / exp_by_inv_alpha, element-wise
+        assert (A.exp_alpha_batch(field, raw[:, 0], inverse=inverse) == A.exp_alpha_batch(field, st[:, 0], inverse=inverse)).all()
+    prep = g_raw.prepare(0)
+    d = torch.from_numpy(raw.view(np.int64).reshape(-1).copy()).to("cuda:0")
+    prep.permutation_dev(d.data_ptr(), len(raw), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (d.cpu().numpy().view(np.uint64).reshape(want.shape) == want).all()
+    prep.close()
+
+
 @pytest.mark.parametrize("field", ["bls12_377", "bn_254", "jubjub"])
 def test_generic_sponge_vs_oracle(A, R, oracle, field):
     rngb = np.random.default_rng(5)
