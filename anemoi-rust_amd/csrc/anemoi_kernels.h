@@ -827,8 +827,9 @@ const FieldOps* field_ops(int field);  // capi.hip
 // UNDERFILLED LAUNCHES GET A DO-NOTHING LAUNCH IN FRONT (round 6; tools/exp_cfg3_after_other_kernels.py, exp_balance_launch.py,
 // exp_balance_launch2.py; profiles/r06/underfilled_launch_placement.txt).  A launch whose single-wavefront workgroups all fit
 // the chip at once takes what its fullest SIMD takes, and the dispatcher does not place it evenly when it follows a launch that
-// OVER-filled the chip (16 384 workgroups of another kernel): it stacks three wavefronts on some SIMDs and leaves others with
-// one or none.  Measured, every time: config 3 (2 048 workgroups resident for 333 ms) 485 ms, x 1.46; 1 024 workgroups
+// OVER-filled the chip (16 384 workgroups, of another kernel or of its own): eight workgroups on every CU as it should, but
+// three wavefronts on ~30 of the 1 024 SIMDs and one on as many (tools/ubench/underfilled_after_overfull.hip records the HW_ID
+// of every workgroup: profiles/r06/ubench_underfilled_after_overfull.txt).  Measured, every time: config 3 (2 048 workgroups resident for 333 ms) 485 ms, x 1.46; 1 024 workgroups
 // x 1.84-1.89; 3 072 x 1.31; nothing at <= 512 workgroups or once the launch fills the chip itself.  Round 5 met the process's
 // first launch of it and cured that one with anemoi_warmup; the rule is wider -- a headline launch and config 3 alternating:
 // every config-3 launch slow.  What restores an even placement is ANY launch of <= 8 192 single-wavefront workgroups that
