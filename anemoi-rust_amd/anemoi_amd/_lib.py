@@ -178,7 +178,7 @@ class ClockSampler:
         cs = ClockSampler(device); cs.start(work_stream); ...enqueue work...; cs.finish(work_stream); torch.cuda.synchronize()
         mean_ghz, min_ghz, max_ghz, groups = cs.read()"""
 
-    def __init__(self, device, period_us=2000, max_ms=120000, wait_ms=1000, stream_priorities="auto"):
+    def __init__(self, device, period_us=2000, max_ms=120000, wait_ms=1000, stream_priorities="auto", reuse_streams=True):
         import torch
         self.torch, self.period_us, self.max_ms, self.wait_ms = torch, period_us, max_ms, wait_ms
         self.bytes = lib.anemoi_clock_sampler_bytes()
@@ -194,12 +194,34 @@ class ClockSampler:
         # priority costs the work nothing -- and its stop on a default-priority one (which may share a queue with the
         # work: it is ordered behind the work anyway).  The work (the caller's stream) is assumed to have the default
         # priority.  stream_priorities=None: two default-priority streams, as round 5 did (the A/B).
-        if stream_priorities is None:
-            self.side, self.third = torch.cuda.Stream(device), torch.cuda.Stream(device)
-        else:
+        # AND the streams are used once, and waited for, BEFORE anything is measured, and kept for the next sampler of the
+        # process: the hardware queue behind a stream is created at its first submission, and a queue created while a
+        # launch is in flight disturbs that launch's placement (tools/exp_sampler_priority_placement.py: config 3 488 ms
+        # instead of 335 behind a sampler whose queue was new, back to back; never behind one whose queue existed).
+        if os.environ.get("ANEMOI_SAMPLER_STREAMS") == "default":      # (the A/B from outside: tools/measure_cycles.py)
+            stream_priorities = None
+        if stream_priorities == "auto":
             lo, hi = self.priority_range()
-            side_p, third_p = (hi, lo) if stream_priorities == "auto" else stream_priorities
-            self.side, self.third = torch.cuda.Stream(device, priority=side_p), torch.cuda.Stream(device, priority=third_p)
+            stream_priorities = (hi, lo)
+        key = (str(device), stream_priorities)
+        ent = ClockSampler._streams.get(key) if reuse_streams else None      # (reuse_streams=False: the experiments)
+        if ent is None or ent["busy"]:
+            if stream_priorities is None:
+                pair = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+            else:
+                pair = (torch.cuda.Stream(device, priority=stream_priorities[0]), torch.cuda.Stream(device, priority=stream_priorities[1]))
+            for st in pair:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=device)
+                st.synchronize()
+            fresh = {"pair": pair, "busy": False}
+            if ent is None and reuse_streams:
+                ClockSampler._streams[key] = fresh
+            ent = fresh
+        self._ent = ent
+        self.side, self.third = ent["pair"]
+
+    _streams = {}
 
     @staticmethod
     def priority_range():
@@ -212,6 +234,7 @@ class ClockSampler:
         return least, greatest
 
     def start(self, work_stream):
+        self._ent["busy"] = True
         self.side.wait_stream(self.torch.cuda.current_stream())     # (the buffers were zero-filled on the current stream)
         _check(lib.anemoi_clock_sampler_start_dev(self.buf.data_ptr(), self.bytes, self.period_us, self.max_ms, self.side.cuda_stream))
         # the work starts once the sampler runs: the wait ends with the sampler's first sample, so a generous bound costs
@@ -229,7 +252,8 @@ class ClockSampler:
         _check(lib.anemoi_clock_sampler_stop_dev(self.buf.data_ptr(), self.third.cuda_stream))
 
     def read(self):
-        host = self.buf.cpu().numpy()
+        host = self.buf.cpu().numpy()       # (waits for the device: the sampler has been stopped, its streams are free again)
+        self._ent["busy"] = False
         st = self.stamps.cpu().numpy().view(np.uint64)
         v = [ctypes.c_double(0) for _ in range(3)]
         g = ctypes.c_int(0)

@@ -22,7 +22,7 @@ def A():
 
 
 # millions of cycles of the slowest XCD per launch.  Measured on the final sources (profiles/r06/cycles_budget.json, the fastest
-# of 5 repetitions): headline 227.7, config 3 783.3, config 5's widest level 77.4; across the round's boxes and sessions
+# of 5 repetitions): headline 227.7, config 3 782.6, config 5's widest level 77.4; across the round's boxes and sessions
 # 227.0-229.6 / 783-787 / 77.4-77.6.  Budget = the top of that range + 2 % (headline: + 1.5 %, the review's 233).
 # The BENCH LINE's figure is the MEAN of its timed steps x the mean of the clock over them, and the first step after an
 # idle phase runs at a lower clock for its first tens of milliseconds (per step 104.6, 99.4, 97.9, 97.8 ms in

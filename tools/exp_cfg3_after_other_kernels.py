@@ -10,7 +10,7 @@ in one process:
     cfg3 x 3 | headline x 2, cfg3 x 2 | jubjub 2^20 x 2, cfg3 x 2 | small cfg3-kernel launch (4 096 messages), cfg3 x 2
     | headline x 2, small launch, cfg3 x 2 | sampler beside: cfg3 x 2 | headline x 2, sampler beside: cfg3 x 2
 
-    python tools/exp_cfg3_after_other_kernels.py [api_warmup] [no_balance]
+    python tools/exp_cfg3_after_other_kernels.py [api_warmup] [no_balance] [sampler_default_priority]
 """
 import os
 import sys
@@ -76,13 +76,21 @@ def main():
     for pre in (False, True):
         if pre:
             show("headline x 2", [headline() for _ in range(2)])
-        cs = A.ClockSampler(dev)
+        cs = A.ClockSampler(dev, stream_priorities=None if "sampler_default_priority" in sys.argv else "auto")
         cs.start(st)
         vals = [cfg3() for _ in range(2)]
         cs.finish(st)
         torch.cuda.synchronize()
         show("%sclock sampler beside: config 3 x 2 (sampled clock min %.3f GHz)" % ("  then " if pre else "", cs.read()[1]), vals)
     show("headline x 1, config 3 x 1, alternating three times", [f() for _ in range(3) for f in (headline, cfg3)])
+    for rep in range(4):      # what tools/measure_cycles.py does: headline launches, ONE config-3 launch, then the sampler and config 3
+        vals = [headline() for _ in range(3)] + [cfg3()]
+        cs = A.ClockSampler(dev, stream_priorities=None if "sampler_default_priority" in sys.argv else "auto")
+        cs.start(st)
+        vals += [cfg3() for _ in range(2)]
+        cs.finish(st)
+        torch.cuda.synchronize()
+        show("headline x 3, config 3, then sampler beside config 3 x 2", vals[3:])
 
 
 if __name__ == "__main__":

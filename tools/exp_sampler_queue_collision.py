@@ -44,7 +44,7 @@ def main():
                 keep = torch.cuda.Stream(dev)          # what other code in a process does: the round-robin shifts by one
                 with torch.cuda.stream(keep):
                     torch.zeros(8, device=dev)
-            cs = A.ClockSampler(dev, period_us=100, max_ms=20000, stream_priorities=None if prio == "odd" else prio)   # a full log = 0.41 s
+            cs = A.ClockSampler(dev, period_us=100, max_ms=20000, stream_priorities=None if prio == "odd" else prio, reuse_streams=False)   # a full log = 0.41 s
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             cs.start(work)
