@@ -9,8 +9,9 @@
                 lengths in one batch (byte messages, and hash_field's element messages), the segment-fed host path (tiny forced segments)
   generic       the run-time-instance kernels fed with the shipped constants (3 fields)
 
-Structured states stress carry patterns: limbs of all ones, values next to p and to 2^k, sparse values.  Kernels are
-forced through anemoi_set_option.  `run()` is what tests/test_gpu_fuzz.py calls (fixed seed, small sizes);
+Structured states stress carry patterns: limbs of all ones, values next to p and to 2^k, sparse values; every third element the
+GPU receives is UNREDUCED (X + k p up to the top of the 64 L-bit range: round 6's input contract) while the oracle keeps X.
+Kernels are forced through anemoi_set_option.  `run()` is what tests/test_gpu_fuzz.py calls (fixed seed, small sizes);
 
     python tools/fuzz_gpu_vs_oracle.py [items_per_field] [seed]
 
@@ -54,6 +55,16 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
     oracle = orc.Oracle()
     failed = []
 
+    def lifted(arr, p, L, rng):
+        """round 6's input contract (any 64 L-bit pattern is taken mod p): every third element of what the GPU gets is
+        X + k p, k up to the top of the 64 L-bit range; the oracle keeps the reduced X"""
+        flat = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, L).copy()
+        room = ((1 << (64 * L)) - 1) // p
+        idx = list(range(seed % 3, len(flat), 3))
+        vals = A.limbs_to_ints(flat[idx])
+        flat[idx] = A.ints_to_limbs([v + rng.randrange(1, room) * p for v in vals], L)
+        return flat.reshape(np.shape(arr))
+
     def check(ok, what):
         if not ok:
             failed.append(what)
@@ -74,6 +85,7 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
             st = oracle.ints_to_mont(fid, items).reshape(cnt, width, L)
             inst = A.Anemoi(field, width)
             exp = oracle.compress_batch(fid, width, st, threads=threads)
+            st_red, st = st, lifted(st, p, L, rng)          # the GPU gets unreduced patterns, the oracle got the reduced ones
             msg = "%-16s W=%d %6d items:" % (field, width, cnt)
             if width == 2:
                 with A.options(**LANE):
@@ -89,7 +101,7 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
                     with A.options(coop_max=BIG, coop2d_max=0, coop4_max=0):
                         msg += "  one-per-wave(%d) %s" % (m, check((inst.compress_batch(st[:m]) == exp[:m]).all(), (field, width, "one-per-wave")))
             else:
-                exp4 = oracle.compress_batch(fid, 4, st, k=4, threads=threads)
+                exp4 = oracle.compress_batch(fid, 4, st_red, k=4, threads=threads)
                 with A.options(**LANE):
                     ok = (inst.compress_batch(st) == exp).all() and (inst.compress_k_batch(st, 4) == exp4).all()
                 msg += " lane-pair %s" % check(ok, (field, width, "lane-pair"))
@@ -103,7 +115,7 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
                 msg += "  two-row(%d) k=2,4 %s" % (m, check(ok, (field, width, "two-row 4-3")))
             m = min(cnt, 256)
             pg = inst.permutation_batch(st[:m])
-            ok = all((pg[i] == oracle.permutation(fid, width, st[i])).all() for i in range(0, m, 5))
+            ok = all((pg[i] == oracle.permutation(fid, width, st_red[i])).all() for i in range(0, m, 5))
             msg += "  permutation %s" % check(ok, (field, width, "permutation"))
             log(msg)
     # sponge: random byte messages of structured lengths (around the chunk and rate-block boundaries)
@@ -143,6 +155,8 @@ def run(n2=20000, n4=5000, seed=1, threads=16, log=print, generic=True):
             emsgs = [oracle.ints_to_mont(fid, [sv[(7 * k + i) % len(sv)] for i in range(k)]).reshape(k, inst.limbs)
                      for k in list(range(0, 3 * r + 2)) * 3]
             ewant = np.stack([oracle.hash_field(fid, width, m) for m in emsgs])
+            erng = random.Random(31 * seed + fid)
+            emsgs = [lifted(m, pval, inst.limbs, erng) if len(m) else m for m in emsgs]      # (unreduced elements: see lifted)
             ok = ok and (inst.hash_field_ragged(emsgs) == ewant).all()
             with A.options(coop2d_max=0, coop2d43_max=0):
                 ok = ok and (inst.hash_field_ragged(emsgs) == ewant).all()
