@@ -699,6 +699,40 @@ def test_warmup_and_issue_rate_probe(A, oracle):
     assert A.lib.anemoi_probe_issue_rate(99, *[ctypes.byref(x) for x in v]) == -4
 
 
+def test_clock_sampler_never_shares_a_queue_with_the_work(A):
+    """Round 6 (profiles/r06/sampler_queue_collision.txt): HIP multiplexes the streams of one priority onto four hardware queues,
+    round-robin in creation order, and serialises streams that share one; the sampler kernel never ends by itself, so a sampler
+    whose stream landed on the work's queue made the work wait until its log was full (seconds) and then run unsampled -- every
+    fourth sampler of round 5's stream set-up as soon as other code took a stream in between.  Twelve samplers in a row, another
+    stream taken (and used) before each, fresh streams for every sampler (the worst case: reuse_streams=False): every one must
+    see the work, and no piece may take longer than the work does."""
+    import torch
+    dev = torch.device("cuda", 0)
+    work = torch.cuda.current_stream()
+    jub = FIELD_IDS.index("jubjub")
+    big = np.random.default_rng(6).integers(0, 1 << 60, size=(1 << 17, 2, 4), dtype=np.uint64)
+    d_in = torch.from_numpy(big.view(np.int64).reshape(-1)).to(dev)
+    d_out = torch.zeros((1 << 17) * 4, dtype=torch.int64, device=dev)
+    assert A.lib.anemoi_init(0, jub, 2) == 0
+    keep = []
+    for i in range(12):
+        other = torch.cuda.Stream(dev)                      # what any other code in the process does
+        with torch.cuda.stream(other):
+            torch.zeros(8, device=dev)
+        keep.append(other)
+        cs = A.ClockSampler(dev, period_us=100, max_ms=20000, reuse_streams=False)     # a full log would be 0.41 s
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cs.start(work)
+        for _ in range(6):
+            assert A.lib.anemoi_jive_compress_k_dev(jub, 2, 2, d_in.data_ptr(), d_out.data_ptr(), 1 << 17, work.cuda_stream) == 0
+        cs.finish(work)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        groups = cs.read()[3]
+        assert groups >= 12 and wall < 0.25, (i, groups, wall)       # (26-30 ms on every box so far; a collision: 0.44 s, 0 groups)
+
+
 def test_dev_jive_rejects_overlapping_buffers(A):
     import torch
     fid = FIELD_IDS.index("jubjub")
