@@ -243,16 +243,25 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(max(args.warmup, 0)):
-        step()
-    barrier()
-    d_out.zero_()                          # the check below must see what the TIMED steps wrote
-    torch.cuda.synchronize()
+    # Everything the timed region needs is made BEFORE the warm-up, and the warm-up writes into a buffer of its own: between
+    # the warm-up's last step and the first timed one the GPU then idles only for the barrier and the sampler's start.  A gap
+    # of 5 ms makes the first step 3 % slower (the chip re-enters full load at a lower clock), 1 ms 0.5 %, 0.2 ms nothing
+    # (profiles/r06/first_step_clock.txt); the zero-fill + second synchronise + allocations that used to sit here were ~ms.
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     # the clock the chip holds DURING the timed steps: 16 single-wavefront sampler workgroups on a stream of their own, asleep
     # between samples (anemoi_clock_sampler_*); started and stamped before the clock starts, stopped by the device itself
     # behind the last step
     sampler = None if args.no_clock_sampler else A.ClockSampler(dev)
+    d_warm = torch.empty_like(d_out)       # the check below must see what the TIMED steps wrote: d_out stays zero until then
+
+    def warm_step():
+        rc = A.lib.anemoi_jive_compress_k_dev(fid, WIDTH, 2, d_in.data_ptr(), d_warm.data_ptr(), n, stream.cuda_stream)
+        if rc != 0:
+            raise A.AnemoiError(rc, A.lib.anemoi_last_error().decode())
+
+    for _ in range(max(args.warmup, 0)):
+        warm_step()
+    barrier()
     if sampler:
         sampler.start(stream)
     torch.cuda.current_stream().synchronize()
@@ -269,7 +278,8 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = max_over_ranks(elapsed, dist, dev if backend == "nccl" else None)
-    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
+    step_ms = [a.elapsed_time(b) for a, b in evs]
+    kernel_ms = sum(step_ms) / max(len(step_ms), 1)
     # what THIS GPU delivers of the kernels' instruction right now (outside the timed steps, the chip still under load)
     # (median of three runs of the probes: the squaring probe's rate wanders by +-1 % from run to run on one box)
     probes = sorted((A.probe_issue_rate(local_rank) for _ in range(3)), key=lambda p: p[2])
@@ -342,6 +352,7 @@ def main():
                          "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
                          "traffic_source": prof_src, "csrc_sha256": csrc,
                          "kernel": "k_jive<bls12_381,2,2>", "kernel_ms": kernel_ms,
+                         "kernel_ms_each_step": [round(v, 3) for v in step_ms[:32]],   # (rank 0's; the first step behind the barrier: see above)
                          "algorithmic_bytes_per_launch": BYTES_PER_ITEM * n},
             "alu": {"bound": "valu", "modmul_per_s": MODMUL_PER_ITEM * n / (kernel_ms * 1e-3),
                     "mad_per_item": mad_per_item, "lane_mad_per_s": lane_mad_per_s,

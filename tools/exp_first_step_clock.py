@@ -29,16 +29,23 @@ def main():
     A.warmup("bls12_381", 2, 0)
     step = lambda: A.lib.anemoi_jive_compress_k_dev(0, 2, 2, d_in.data_ptr(), d_out.data_ptr(), n, st.cuda_stream)
     for label, gap in (("after %.0f ms of idling (bench.py's gap: barrier, zero-fill, synchronise)" % idle_ms, idle_ms), ("after 500 ms of idling", 500.0),
-                       ("straight behind three untimed steps (no gap)", 0.0)):
+                       ("straight behind three untimed steps (no gap)", 0.0), ("after 1 ms of idling", 1.0), ("after 0.2 ms of idling", 0.2),
+                       ("synchronise, then launch at once (sampler started before the untimed steps)", -1.0)):
+        cs = A.ClockSampler(dev, period_us=500, max_ms=60000)
+        marks = torch.zeros(steps + 1, dtype=torch.int64, device=dev)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        if gap < 0:
+            cs.start(st)
         for _ in range(3):
             step()
         if gap:
             torch.cuda.synchronize()
-            time.sleep(gap * 1e-3)
-        cs = A.ClockSampler(dev, period_us=500, max_ms=60000)
-        marks = torch.zeros(steps + 1, dtype=torch.int64, device=dev)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        cs.start(st)
+            if gap > 0:
+                t_end = time.perf_counter() + gap * 1e-3
+                while time.perf_counter() < t_end:
+                    pass
+        if gap >= 0:
+            cs.start(st)
         for i, (a, b) in enumerate(evs):
             A.lib.anemoi_clock_stamp_dev(marks.data_ptr() + 8 * i, st.cuda_stream)
             a.record(st)
