@@ -596,8 +596,20 @@ def test_underfilled_launch_is_placed_evenly_whatever_ran_before(A, synth):
     sponge = lambda wgs: timed(lambda: A.lib.anemoi_hash_bytes_dev(bn, 4, msgs.data_ptr(), mlen, wgs * 32, dig.data_ptr(), st.cuda_stream))
     jive = lambda wgs: timed(lambda: A.lib.anemoi_jive_compress_k_dev(bls, 2, 2, d_bls.data_ptr(), o_bls.data_ptr(), wgs * 64, st.cuda_stream))
     disturb = lambda: timed(lambda: A.lib.anemoi_jive_compress_k_dev(jub, 2, 2, d_jub.data_ptr(), o_jub.data_ptr(), n, st.cuda_stream))
-    with knobs(**lane_private):
-        for name, target in (("sponge bn_254 4-3", sponge), ("jive bls12_381 2-1", jive)):
+    # ... and two more launchers of the same shape: the in-place permutation (4-3, lane pairs) and the path climb -- the rule
+    # is about the launch's shape, not about the kernel
+    d_perm = torch.from_numpy(synth.states("bn_254", 4, 7, 0, 2048 * 32).view(np.int64).reshape(-1)).to(dev)
+    depth = 3
+    d_leaf = torch.from_numpy(synth.states("jubjub", 2, 8, 0, 2048 * 32).view(np.int64).reshape(-1)).to(dev)       # 2 048 x 64 leaves
+    d_path = torch.from_numpy(synth.states("jubjub", 2, 9, 0, 2048 * 32 * depth).view(np.int64).reshape(-1)).to(dev)
+    d_idx = torch.from_numpy(rng.integers(0, 1 << depth, size=2048 * 64, dtype=np.uint64).view(np.int64)).to(dev)
+    d_root = torch.empty(2048 * 64 * 4, dtype=torch.int64, device=dev)
+    perm = lambda wgs: timed(lambda: A.lib.anemoi_permutation_dev(bn, 4, d_perm.data_ptr(), wgs * 32, st.cuda_stream))
+    climb = lambda wgs: timed(lambda: A.lib.anemoi_merkle_climb_dev(jub, d_leaf.data_ptr(), d_idx.data_ptr(), d_path.data_ptr(), depth, wgs * 64,
+                                                                    d_root.data_ptr(), st.cuda_stream))
+    with knobs(**lane_private, coop_climb_max=0):
+        for name, target in (("sponge bn_254 4-3", sponge), ("jive bls12_381 2-1", jive), ("permutation bn_254 4-3", perm),
+                             ("path climb jubjub", climb)):
             for wgs in (1024, 2048):
                 target(wgs)
                 steady = min(target(wgs) for _ in range(3))
