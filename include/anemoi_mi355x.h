@@ -97,7 +97,7 @@ enum {
  * are only ADDED.  A caller compiled against (M, m) may use a library that answers 100 x M + m' with m' >= m, and nothing
  * else.  History: 4 (56 functions); 11 functions were added in round 5 without moving it (by this rule: 4.1); 5.0 = the two
  * `_ragged_bucketed_dev` forms take the extent of the message blob and leave a status word in the scratch, whose size grew
- * by 16 bytes (67 functions). */
+ * by 16 bytes; first version with the options balance_underfilled and lane_priorities (67 functions). */
 #define ANEMOI_ABI_MAJOR 5
 #define ANEMOI_ABI_MINOR 0
 int anemoi_abi_version(void);
